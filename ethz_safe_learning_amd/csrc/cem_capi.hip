@@ -1,0 +1,691 @@
+// cem_capi.hip — host side of the C ABI declared in include/cem_mpc.h.
+// Built with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC (see csrc/build.sh).
+#include "cem_device.h"
+#include "../../include/cem_mpc.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <vector>
+
+static thread_local int g_last_hip = 0;
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_last_hip = (int)e_; return CEM_ERR_HIP; } } while (0)
+
+namespace {
+
+struct Dims {
+    int O, A, Din, U, L, E, P, N, H, k, I, W, R;
+    int Nloc, n_off, Bloc, Btot;
+    int KB_in, KB_obs, NFW;
+    int wave_groups[4]; uint32_t wave_off_f4[4]; uint32_t member_stride_f4;
+    size_t nat_member_floats;
+};
+
+int validate(const cem_config_t *c)
+{
+    if (!c) return CEM_ERR_INVALID_ARG;
+    if (c->abi_version != CEM_ABI_VERSION) return CEM_ERR_INVALID_ARG;
+    if (c->obs_dim < 1 || c->act_dim < 1 || c->act_dim > CEM_MAX_ACT || c->n_layers < 1 || c->ensemble_size < 1 ||
+        c->particles < 1 || c->n_samples < 1 || c->horizon < 1 || c->horizon > 65535 || c->iterations < 1 || c->iterations > 65535 ||
+        c->n_elite < 1 || c->n_elite > c->n_samples || c->world_size < 1 || c->rank < 0 || c->rank >= c->world_size)
+        return CEM_ERR_INVALID_ARG;
+    if (c->units != CEM_U) return CEM_ERR_UNSUPPORTED;
+    if (c->obs_dim + c->act_dim > CEM_U) return CEM_ERR_UNSUPPORTED;
+    if (c->n_samples % c->world_size != 0) return CEM_ERR_INVALID_ARG;
+    if (((long long)c->particles * c->n_samples) % c->ensemble_size != 0) return CEM_ERR_SPLIT;
+    if (c->n_elite > 24576) return CEM_ERR_UNSUPPORTED;
+    if (c->scorer.n_cost_kinds < 0 || c->scorer.n_cost_kinds > CEM_MAX_COST_KINDS) return CEM_ERR_INVALID_ARG;
+    if (c->variant != CEM_VARIANT_CEM && c->variant != CEM_VARIANT_SAFE) return CEM_ERR_INVALID_ARG;
+    if (c->chunks_per_tile < 0 || c->chunks_per_tile > 4) return CEM_ERR_INVALID_ARG;
+    if ((long long)c->particles * c->n_samples > (1ll << 30)) return CEM_ERR_UNSUPPORTED;
+    return CEM_OK;
+}
+
+Dims make_dims(const cem_config_t *c)
+{
+    Dims d{};
+    d.O = c->obs_dim; d.A = c->act_dim; d.Din = d.O + d.A; d.U = c->units; d.L = c->n_layers; d.E = c->ensemble_size;
+    d.P = c->particles; d.N = c->n_samples; d.H = c->horizon; d.k = c->n_elite; d.I = c->iterations;
+    d.W = c->world_size; d.R = c->rank;
+    d.Nloc = d.N / d.W; d.n_off = d.R * d.Nloc; d.Bloc = d.P * d.Nloc; d.Btot = d.P * d.N;
+    d.KB_in = (d.Din + 15) / 16; d.KB_obs = (d.O + 15) / 16; d.NFW = (d.KB_in + 3) / 4;
+    uint32_t off = 0;
+    for (int w = 0; w < 4; ++w) {
+        int g = d.KB_in + CEM_NG * (d.L - 1);
+        for (int i = 0; i < d.NFW; ++i) if (w + 4 * i < d.KB_obs) g += CEM_NG;
+        d.wave_groups[w] = g; d.wave_off_f4[w] = off; off += (uint32_t)g * 128u;
+    }
+    d.member_stride_f4 = off + 256u;    // +2 groups of slack: the prefetch queue may run ahead of a short stream
+    d.nat_member_floats = (size_t)d.Din * d.U + d.U + (size_t)(d.L - 1) * ((size_t)d.U * d.U + d.U) + 2 * ((size_t)d.U * d.O + d.O);
+    return d;
+}
+
+// natural blob offsets of one member
+struct NatOff { std::vector<size_t> W, b; size_t Wmu, bmu, Wvar, bvar; };
+NatOff nat_offsets(const Dims &d)
+{
+    NatOff n; size_t o = 0; int fi = d.Din;
+    for (int l = 0; l < d.L; ++l) { n.W.push_back(o); o += (size_t)fi * d.U; n.b.push_back(o); o += d.U; fi = d.U; }
+    n.Wmu = o; o += (size_t)d.U * d.O; n.bmu = o; o += d.O; n.Wvar = o; o += (size_t)d.U * d.O; n.bvar = o;
+    return n;
+}
+
+// Weight stream of (member, wave): A-operand order of v_mfma_f32_16x16x4_f32 for out^T = W^T h^T.
+// group = [g(2)][lane(64)][r(4)]; lane = 16*kq + i holds W[k = 16F + 4kq + r][out = 16G + i]: the k-quad of
+// MFMA step (F, r) is {16F + r, 16F+4 + r, 16F+8 + r, 16F+12 + r}, i.e. exactly what accumulator register r
+// of the producing layer holds across the four lane groups.
+void pack_member(const Dims &d, const float *nat, float *out)
+{
+    const NatOff no = nat_offsets(d);
+    std::memset(out, 0, (size_t)d.member_stride_f4 * 4 * sizeof(float));
+    for (int w = 0; w < 4; ++w) {
+        float *dst = out + (size_t)d.wave_off_f4[w] * 4;
+        auto emit = [&](const float *W, int in_dim, int out_dim, int ld, int F, int g, int Gout) {
+            for (int lane = 0; lane < 64; ++lane) {
+                const int kq = lane >> 4, i = lane & 15;
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 16 * F + 4 * kq + r, o = 16 * Gout + i;
+                    dst[((size_t)g * 64 + lane) * 4 + r] = (k < in_dim && o < out_dim) ? W[(size_t)k * ld + o] : 0.f;
+                }
+            }
+        };
+        for (int F = 0; F < d.KB_in; ++F) {                       // layer 0
+            emit(nat + no.W[0], d.Din, d.U, d.U, F, 0, 2 * w); emit(nat + no.W[0], d.Din, d.U, d.U, F, 1, 2 * w + 1);
+            dst += 512;
+        }
+        for (int l = 1; l < d.L; ++l)
+            for (int F = 0; F < CEM_NG; ++F) {
+                emit(nat + no.W[l], d.U, d.U, d.U, F, 0, 2 * w); emit(nat + no.W[l], d.U, d.U, d.U, F, 1, 2 * w + 1);
+                dst += 512;
+            }
+        for (int i = 0; i < d.NFW; ++i) {
+            const int Fo = w + 4 * i;
+            if (Fo >= d.KB_obs) continue;
+            for (int F = 0; F < CEM_NG; ++F) {                    // heads: g=0 mu, g=1 var of obs block Fo
+                emit(nat + no.Wmu, d.U, d.O, d.O, F, 0, Fo); emit(nat + no.Wvar, d.U, d.O, d.O, F, 1, Fo);
+                dst += 512;
+            }
+        }
+    }
+}
+
+struct Tile6 { int32_t v[6]; };
+
+// tiles of one particle-major row space.  Rows r = p*nstride + n (n in [n_lo, n_hi)) use member
+// (p*N + n) / chunk; a tile never straddles a member boundary (mlp_ensemble.py:123-126).
+void build_plan_tiles(const Dims &d, int rc, std::vector<Tile6> &out)
+{
+    out.clear();
+    const long long chunk = (long long)d.Btot / d.E;
+    const int rows_per_tile = 16 * rc;
+    for (int p = 0; p < d.P; ++p) {
+        int n = d.n_off; const int n_end = d.n_off + d.Nloc;
+        while (n < n_end) {
+            const long long rg = (long long)p * d.N + n;
+            const int member = (int)(rg / chunk);
+            const long long seg_end_g = std::min<long long>((long long)(member + 1) * chunk, (long long)p * d.N + n_end);
+            const int seg = (int)(seg_end_g - rg);
+            const int ntile = (seg + rows_per_tile - 1) / rows_per_tile;
+            int done = 0;
+            for (int t = 0; t < ntile; ++t) {
+                const int cnt = (seg - done + (ntile - t) - 1) / (ntile - t);     // even split
+                Tile6 td; td.v[0] = p * d.Nloc + (n - d.n_off) + done; td.v[1] = cnt; td.v[2] = member;
+                td.v[3] = n + done; td.v[4] = (int)(rg + done); td.v[5] = -1;
+                out.push_back(td); done += cnt;
+            }
+            n += seg;
+        }
+    }
+    // XCD-aware order: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch), so give each XCD a
+    // contiguous range of tiles = as few members (weight sets) as possible per private L2.
+    const int T = (int)out.size();
+    std::vector<Tile6> perm(T);
+    const int qd = T / 8, rm = T % 8;
+    for (int b = 0; b < T; ++b) {
+        const int xcd = b % 8, slot = b / 8;
+        const int base = xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd;
+        perm[b] = out[base + slot];
+    }
+    out.swap(perm);
+}
+
+int auto_chunks(const Dims &d)
+{
+    // makespan model: 256 CUs, tile cost ~ (rc + fixed overhead of barriers/epilogue)
+    int best = 1; double bestc = 1e30;
+    for (int rc = 1; rc <= 4; ++rc) {
+        std::vector<Tile6> t; build_plan_tiles(d, rc, t);
+        const double waves = std::ceil((double)t.size() / 256.0);
+        const double cost = waves * (rc + 0.35);
+        if (cost < bestc - 1e-9) { bestc = cost; best = rc; }
+    }
+    return best;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Layout {
+    size_t ctrl, musig, scores_local, scores_global, actions, elite, returns, costs, result, wpack, bias_h, bias_mu, bias_var,
+        nmin, ndelta, tiles, eps_out, total;
+};
+
+Layout make_layout(const cem_config_t *c, const Dims &d, size_t max_tiles)
+{
+    Layout l{}; size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
+    l.ctrl = take(sizeof(CtrlBlock));
+    l.musig = take((size_t)2 * d.H * d.A * 4);
+    l.scores_local = take((size_t)d.Nloc * 4);
+    l.scores_global = d.W > 1 ? take((size_t)d.N * 4) : l.scores_local;
+    l.actions = take((size_t)d.N * d.H * d.A * 4);
+    l.elite = take((size_t)d.k * 4);
+    l.returns = take((size_t)d.Bloc * 4);
+    l.costs = take((size_t)d.H * d.Bloc);
+    l.result = take(64 * 4);
+    l.wpack = take((size_t)d.E * d.member_stride_f4 * 16);
+    l.bias_h = take((size_t)d.E * d.L * CEM_U * 4);
+    l.bias_mu = take((size_t)d.E * CEM_U * 4);
+    l.bias_var = take((size_t)d.E * CEM_U * 4);
+    l.nmin = take(CEM_U * 4);
+    l.ndelta = take(CEM_U * 4);
+    l.tiles = take(max_tiles * sizeof(TileDesc));
+    l.eps_out = take(CEM_MAX_ACT * 4);
+    l.total = o;
+    (void)c;
+    return l;
+}
+
+size_t max_tiles_of(const Dims &d) { std::vector<Tile6> t; build_plan_tiles(d, 1, t); return t.size(); }
+
+}  // namespace
+
+struct cem_planner {
+    cem_config_t cfg;
+    Dims d;
+    Layout lay;
+    char *ws;
+    hipStream_t stream;
+    int rc;
+    int n_tiles;
+    bool have_weights;
+    bool in_plan;
+    const float *eps_act, *eps_model;       // current plan's explicit noise (device) or null
+    // pinned host staging
+    CtrlBlock *h_ctrl;
+    float *h_result;
+    // timing
+    bool timing; std::vector<hipEvent_t> ev; float roll_ms, sel_ms; int roll_n;
+    std::vector<std::pair<int, int>> ev_kind;   // (event index of start, kind 0 rollout / 1 select)
+    // graph
+    hipGraph_t graph; hipGraphExec_t gexec; bool graph_ready;
+    ScorerDev sc;
+    float alpha, beta;
+};
+
+extern "C" {
+
+int cem_abi_version(void) { return CEM_ABI_VERSION; }
+int cem_last_hip_error(void) { return g_last_hip; }
+
+const char *cem_status_string(int s)
+{
+    switch (s) {
+    case CEM_OK: return "ok";
+    case CEM_ERR_INVALID_ARG: return "invalid argument";
+    case CEM_ERR_UNSUPPORTED: return "unsupported configuration (units must be 128, obs+act <= 128, task 'goal')";
+    case CEM_ERR_SPLIT: return "particles*n_samples is not divisible by ensemble_size (tf.split would raise)";
+    case CEM_ERR_WORKSPACE: return "workspace too small or misaligned";
+    case CEM_ERR_HIP: return "HIP runtime error (see cem_last_hip_error)";
+    case CEM_ERR_NO_WEIGHTS: return "set_weights has not been called";
+    case CEM_ERR_STATE: return "stepwise plan calls out of order";
+    default: return "unknown status";
+    }
+}
+
+size_t cem_weight_blob_floats(const cem_config_t *cfg)
+{
+    if (validate(cfg) != CEM_OK) return 0;
+    const Dims d = make_dims(cfg);
+    return d.nat_member_floats * d.E;
+}
+
+size_t cem_packed_weight_floats(const cem_config_t *cfg)
+{
+    if (validate(cfg) != CEM_OK) return 0;
+    const Dims d = make_dims(cfg);
+    return (size_t)d.member_stride_f4 * 4 * d.E;
+}
+
+size_t cem_workspace_bytes(const cem_config_t *cfg)
+{
+    if (validate(cfg) != CEM_OK) return 0;
+    const Dims d = make_dims(cfg);
+    return make_layout(cfg, d, max_tiles_of(d)).total;
+}
+
+int cem_pack_weights_host(const cem_config_t *cfg, const float *blob, float *packed)
+{
+    int st = validate(cfg); if (st) return st;
+    if (!blob || !packed) return CEM_ERR_INVALID_ARG;
+    const Dims d = make_dims(cfg);
+    for (int m = 0; m < d.E; ++m) pack_member(d, blob + (size_t)m * d.nat_member_floats, packed + (size_t)m * d.member_stride_f4 * 4);
+    return CEM_OK;
+}
+
+int cem_plan_tiles_host(const cem_config_t *cfg, int32_t *rc_out, int32_t *n_tiles_out, int32_t *tiles_out, int32_t max_tiles)
+{
+    int st = validate(cfg); if (st) return st;
+    const Dims d = make_dims(cfg);
+    const int rc = cfg->chunks_per_tile ? cfg->chunks_per_tile : auto_chunks(d);
+    std::vector<Tile6> t; build_plan_tiles(d, rc, t);
+    if (rc_out) *rc_out = rc;
+    if (n_tiles_out) *n_tiles_out = (int32_t)t.size();
+    if (tiles_out) {
+        if ((int)t.size() > max_tiles) return CEM_ERR_INVALID_ARG;
+        std::memcpy(tiles_out, t.data(), t.size() * sizeof(Tile6));
+    }
+    return CEM_OK;
+}
+
+int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspace_bytes, void *hip_stream, cem_planner_t **out)
+{
+    int st = validate(cfg); if (st) return st;
+    if (!workspace || !out) return CEM_ERR_INVALID_ARG;
+    cem_planner *h = new (std::nothrow) cem_planner();
+    if (!h) return CEM_ERR_INVALID_ARG;
+    h->cfg = *cfg; h->d = make_dims(cfg);
+    h->lay = make_layout(cfg, h->d, max_tiles_of(h->d));
+    if (workspace_bytes < h->lay.total || ((uintptr_t)workspace & 255)) { delete h; return CEM_ERR_WORKSPACE; }
+    h->ws = (char *)workspace; h->stream = (hipStream_t)hip_stream;
+    h->rc = cfg->chunks_per_tile ? cfg->chunks_per_tile : auto_chunks(h->d);
+    h->have_weights = false; h->in_plan = false; h->eps_act = h->eps_model = nullptr;
+    h->timing = false; h->roll_ms = h->sel_ms = 0.f; h->roll_n = 0;
+    h->graph = nullptr; h->gexec = nullptr; h->graph_ready = false;
+    h->h_ctrl = nullptr; h->h_result = nullptr;
+    if (hipHostMalloc((void **)&h->h_ctrl, sizeof(CtrlBlock), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&h->h_result, 64 * 4, hipHostMallocDefault) != hipSuccess) { g_last_hip = (int)hipGetLastError(); delete h; return CEM_ERR_HIP; }
+    std::memset(h->h_ctrl, 0, sizeof(CtrlBlock));
+
+    // scorer constants, rounded the way the reference's Python-float -> fp32 tensor conversion rounds them
+    const cem_scorer_t &s = cfg->scorer;
+    ScorerDev &sc = h->sc;
+    sc.goal_mode = s.goal_mode; sc.goal_lo = s.goal_lo; sc.goal_hi = s.goal_hi; sc.D = s.lidar_max_dist;
+    sc.goal_thresh = (float)((double)s.goal_size * 0.8);
+    sc.reward_distance = s.reward_distance; sc.reward_goal = s.reward_goal; sc.reward_clip = s.reward_clip;
+    sc.indicator = s.constrain_indicator; sc.n_cost = s.n_cost_kinds;
+    for (int i = 0; i < 4; ++i) { sc.cost_lo[i] = s.cost_lo[i]; sc.cost_hi[i] = s.cost_hi[i]; sc.cost_size[i] = s.cost_size[i]; }
+    {   // Beta prior of safe_cem_mpc.py:113-115 in fp32 tensor arithmetic (mu = 0.5, sigma = 0.27 from :81)
+        const float mu = 0.5f, sg = 0.27f;
+        const float alpha = (((1.0f - mu) / (sg * sg)) - 1.0f / mu) * (mu * mu);
+        h->alpha = alpha; h->beta = alpha * (1.0f / mu - 1.0f);
+    }
+
+    // tiles -> device
+    std::vector<Tile6> tiles; build_plan_tiles(h->d, h->rc, tiles);
+    h->n_tiles = (int)tiles.size();
+    if (hipMemcpyAsync(h->ws + h->lay.tiles, tiles.data(), tiles.size() * sizeof(Tile6), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) { g_last_hip = (int)hipGetLastError(); hipHostFree(h->h_ctrl); hipHostFree(h->h_result); delete h; return CEM_ERR_HIP; }
+    // identity normaliser until set_normaliser is called
+    std::vector<float> mn(CEM_U, 0.f), dl(CEM_U, 1.f);
+    hipMemcpyAsync(h->ws + h->lay.nmin, mn.data(), CEM_U * 4, hipMemcpyHostToDevice, h->stream);
+    hipMemcpyAsync(h->ws + h->lay.ndelta, dl.data(), CEM_U * 4, hipMemcpyHostToDevice, h->stream);
+    hipStreamSynchronize(h->stream);
+    *out = h;
+    return CEM_OK;
+}
+
+int cem_planner_destroy(cem_planner_t *h)
+{
+    if (!h) return CEM_ERR_INVALID_ARG;
+    if (h->gexec) hipGraphExecDestroy(h->gexec);
+    if (h->graph) hipGraphDestroy(h->graph);
+    for (auto e : h->ev) hipEventDestroy(e);
+    if (h->h_ctrl) hipHostFree(h->h_ctrl);
+    if (h->h_result) hipHostFree(h->h_result);
+    delete h;
+    return CEM_OK;
+}
+
+int cem_planner_layout(const cem_planner_t *h, cem_layout_t *o)
+{
+    if (!h || !o) return CEM_ERR_INVALID_ARG;
+    o->scores_local = h->lay.scores_local; o->scores_global = h->lay.scores_global; o->actions = h->lay.actions;
+    o->mu_sigma = h->lay.musig; o->elite_idx = h->lay.elite; o->returns = h->lay.returns; o->costs = h->lay.costs;
+    o->result = h->lay.result; o->total = h->lay.total;
+    return CEM_OK;
+}
+
+int cem_planner_set_weights(cem_planner_t *h, const float *blob, size_t n_floats)
+{
+    if (!h || !blob) return CEM_ERR_INVALID_ARG;
+    const Dims &d = h->d;
+    if (n_floats != d.nat_member_floats * d.E) return CEM_ERR_INVALID_ARG;
+    std::vector<float> packed((size_t)d.member_stride_f4 * 4 * d.E);
+    std::vector<float> bh((size_t)d.E * d.L * CEM_U, 0.f), bmu((size_t)d.E * CEM_U, 0.f), bvar((size_t)d.E * CEM_U, 0.f);
+    const NatOff no = nat_offsets(d);
+    for (int m = 0; m < d.E; ++m) {
+        const float *nat = blob + (size_t)m * d.nat_member_floats;
+        pack_member(d, nat, packed.data() + (size_t)m * d.member_stride_f4 * 4);
+        for (int l = 0; l < d.L; ++l) std::memcpy(&bh[((size_t)m * d.L + l) * CEM_U], nat + no.b[l], d.U * 4);
+        std::memcpy(&bmu[(size_t)m * CEM_U], nat + no.bmu, d.O * 4);
+        std::memcpy(&bvar[(size_t)m * CEM_U], nat + no.bvar, d.O * 4);
+    }
+    HIPCHK(hipMemcpyAsync(h->ws + h->lay.wpack, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->ws + h->lay.bias_h, bh.data(), bh.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->ws + h->lay.bias_mu, bmu.data(), bmu.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->ws + h->lay.bias_var, bvar.data(), bvar.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->have_weights = true;
+    return CEM_OK;
+}
+
+int cem_planner_set_normaliser(cem_planner_t *h, const float *imin, const float *imax)
+{
+    if (!h || !imin || !imax) return CEM_ERR_INVALID_ARG;
+    const Dims &d = h->d;
+    std::vector<float> mn(CEM_U, 0.f), dl(CEM_U, 1.f);
+    if (h->cfg.scale_features) {                      // transition_model.py:79-87
+        for (int f = 0; f < d.Din; ++f) {
+            float delta = imax[f] - imin[f];
+            if (delta < 1e-5f) delta = 1.01f;
+            mn[f] = imin[f]; dl[f] = delta;
+        }
+    }
+    HIPCHK(hipMemcpyAsync(h->ws + h->lay.nmin, mn.data(), CEM_U * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->ws + h->lay.ndelta, dl.data(), CEM_U * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CEM_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// launches
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+template <int RC, int NFW, bool DBG>
+hipError_t launch_rollout_t(const RolloutParams &p, int n_tiles, hipStream_t st)
+{
+    const size_t lds = (size_t)2 * RC * CEM_NG * 1024 + CEM_PART_FLOATS * 4;
+    hipLaunchKernelGGL((cem_rollout_kernel<RC, NFW, DBG>), dim3(n_tiles), dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+
+template <bool DBG>
+hipError_t launch_rollout(int rc, int nfw, const RolloutParams &p, int n_tiles, hipStream_t st)
+{
+#define CEM_CASE(R, F) if (rc == R && nfw == F) return launch_rollout_t<R, F, DBG>(p, n_tiles, st);
+    CEM_CASE(1, 1) CEM_CASE(2, 1) CEM_CASE(3, 1) CEM_CASE(4, 1)
+    CEM_CASE(1, 2) CEM_CASE(2, 2) CEM_CASE(3, 2) CEM_CASE(4, 2)
+#undef CEM_CASE
+    return hipErrorInvalidValue;
+}
+
+void fill_rollout_common(const cem_planner *h, RolloutParams &p)
+{
+    const Dims &d = h->d; const Layout &l = h->lay; char *ws = h->ws;
+    std::memset(&p, 0, sizeof(p));
+    p.wpack = (const f4 *)(ws + l.wpack); p.bias_h = (const float *)(ws + l.bias_h);
+    p.bias_mu = (const float *)(ws + l.bias_mu); p.bias_var = (const float *)(ws + l.bias_var);
+    p.nmin = (const float *)(ws + l.nmin); p.ndelta = (const float *)(ws + l.ndelta);
+    p.ctrl = (const CtrlBlock *)(ws + l.ctrl);
+    p.member_stride_f4 = d.member_stride_f4;
+    for (int w = 0; w < 4; ++w) { p.wave_off_f4[w] = d.wave_off_f4[w]; p.wave_groups[w] = (uint32_t)d.wave_groups[w]; }
+    p.O = d.O; p.A = d.A; p.L = d.L; p.KB_in = d.KB_in; p.KB_obs = d.KB_obs;
+    p.sampling = h->cfg.sampling_propagation; p.sc = h->sc;
+}
+
+hipEvent_t get_event(cem_planner *h, size_t i)
+{
+    while (h->ev.size() <= i) { hipEvent_t e; hipEventCreate(&e); h->ev.push_back(e); }
+    return h->ev[i];
+}
+
+int enqueue_begin(cem_planner *h)
+{
+    const Dims &d = h->d; const Layout &l = h->lay;
+    HIPCHK(hipMemcpyAsync(h->ws + l.ctrl, h->h_ctrl, sizeof(CtrlBlock), hipMemcpyHostToDevice, h->stream));
+    InitParams ip{}; ip.ctrl = (CtrlBlock *)(h->ws + l.ctrl); ip.musig = (float *)(h->ws + l.musig); ip.HA = d.H * d.A; ip.A = d.A;
+    for (int a = 0; a < d.A; ++a) { ip.mu0[a] = h->cfg.act_mu0[a]; ip.sigma0[a] = h->cfg.act_sigma0[a]; }
+    const int n = std::max(ip.HA, 32);
+    hipLaunchKernelGGL(cem_init_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, ip);
+    HIPCHK(hipGetLastError());
+    return CEM_OK;
+}
+
+int enqueue_rollout(cem_planner *h, int it)
+{
+    const Dims &d = h->d; const Layout &l = h->lay; char *ws = h->ws;
+    SampleParams sp{}; sp.actions = (float *)(ws + l.actions); sp.musig = (const float *)(ws + l.musig);
+    sp.eps_act = h->eps_act ? h->eps_act + (size_t)it * d.N * d.H * d.A : nullptr;
+    sp.ctrl = (const CtrlBlock *)(ws + l.ctrl); sp.N = d.N; sp.H = d.H; sp.A = d.A; sp.it = it; sp.check_done = 1;
+    for (int a = 0; a < d.A; ++a) { sp.lb[a] = h->cfg.act_lb[a]; sp.ub[a] = h->cfg.act_ub[a]; }
+    const int total = d.N * d.H * ((d.A + 3) / 4);
+    hipLaunchKernelGGL(cem_sample_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, h->stream, sp);
+    HIPCHK(hipGetLastError());
+
+    RolloutParams rp; fill_rollout_common(h, rp);
+    rp.tiles = (const TileDesc *)(ws + l.tiles); rp.s0 = nullptr; rp.actions = (const float *)(ws + l.actions);
+    rp.eps_model = h->eps_model ? h->eps_model + (size_t)it * d.H * d.Btot * d.O : nullptr;
+    rp.ret = (float *)(ws + l.returns); rp.costs = h->cfg.variant == CEM_VARIANT_SAFE ? (uint8_t *)(ws + l.costs) : nullptr;
+    rp.H = d.H; rp.Bloc = d.Bloc; rp.Btot = d.Btot; rp.it = it; rp.variant = h->cfg.variant; rp.check_done = 1;
+    size_t e0 = 0;
+    if (h->timing) { e0 = h->ev_kind.size() * 2; h->ev_kind.push_back({(int)e0, 0}); hipEventRecord(get_event(h, e0), h->stream); }
+    HIPCHK(launch_rollout<false>(h->rc, d.NFW, rp, h->n_tiles, h->stream));
+    if (h->timing) hipEventRecord(get_event(h, e0 + 1), h->stream);
+
+    ReduceParams qp{}; qp.ret = rp.ret; qp.costs = rp.costs; qp.scores = (float *)(ws + l.scores_local); qp.ctrl = sp.ctrl;
+    qp.Nloc = d.Nloc; qp.P = d.P; qp.H = d.H; qp.variant = h->cfg.variant; qp.check_done = 1;
+    qp.alpha = h->alpha; qp.beta = h->beta; qp.thr = h->cfg.posterior_mean_threashold;
+    hipLaunchKernelGGL(cem_reduce_kernel, dim3((d.Nloc + 255) / 256), dim3(256), 0, h->stream, qp);
+    HIPCHK(hipGetLastError());
+    return CEM_OK;
+}
+
+int enqueue_select(cem_planner *h, int it)
+{
+    (void)it;
+    const Dims &d = h->d; const Layout &l = h->lay; char *ws = h->ws;
+    SelectParams p{}; p.scores = (const float *)(ws + l.scores_global); p.actions = (const float *)(ws + l.actions);
+    p.musig = (float *)(ws + l.musig); p.ctrl = (CtrlBlock *)(ws + l.ctrl); p.elite_idx = (int32_t *)(ws + l.elite);
+    p.N = d.N; p.k = d.k; p.HA = d.H * d.A; p.A = d.A; p.check_done = 1;
+    p.smoothing = h->cfg.smoothing; p.threshold = h->cfg.stddev_threshold;
+    const size_t lds = (size_t)((d.k + 3) & ~3) * 4 + (size_t)d.H * d.A * 4;
+    size_t e0 = 0;
+    if (h->timing) { e0 = h->ev_kind.size() * 2; h->ev_kind.push_back({(int)e0, 1}); hipEventRecord(get_event(h, e0), h->stream); }
+    hipLaunchKernelGGL(cem_select_kernel, dim3(1), dim3(1024), lds, h->stream, p);
+    HIPCHK(hipGetLastError());
+    if (h->timing) hipEventRecord(get_event(h, e0 + 1), h->stream);
+    return CEM_OK;
+}
+
+int enqueue_end(cem_planner *h, bool have_eps_out)
+{
+    const Dims &d = h->d; const Layout &l = h->lay; char *ws = h->ws;
+    FinalParams fp{}; fp.ctrl = (const CtrlBlock *)(ws + l.ctrl); fp.eps_out = have_eps_out ? (const float *)(ws + l.eps_out) : nullptr;
+    fp.result = (float *)(ws + l.result); fp.A = d.A; fp.noise_stddev = h->cfg.noise_stddev;
+    hipLaunchKernelGGL(cem_final_kernel, dim3(1), dim3(64), 0, h->stream, fp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h->h_result, ws + l.result, 64 * 4, hipMemcpyDeviceToHost, h->stream));
+    return CEM_OK;
+}
+
+void collect_timing(cem_planner *h)
+{
+    h->roll_ms = 0.f; h->sel_ms = 0.f; h->roll_n = 0;
+    for (auto &ek : h->ev_kind) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev[ek.first], h->ev[ek.first + 1]) == hipSuccess) {
+            if (ek.second == 0) { h->roll_ms += ms; h->roll_n++; } else h->sel_ms += ms;
+        }
+    }
+    h->ev_kind.clear();
+}
+
+void stage_ctrl(cem_planner *h, const float *state, uint64_t seed, uint64_t call)
+{
+    CtrlBlock *c = h->h_ctrl;
+    c->seed_lo = (uint32_t)seed; c->seed_hi = (uint32_t)(seed >> 32); c->call_lo = (uint32_t)call; c->call_hi = (uint32_t)(call >> 32);
+    c->done = 0; c->iters = 0; c->best_score = -std::numeric_limits<float>::infinity();
+    for (int f = 0; f < CEM_U; ++f) c->state[f] = f < h->d.O ? state[f] : 0.f;
+    for (int a = 0; a < 32; ++a) c->best[a] = 0.f;
+}
+
+void read_result(cem_planner *h, float *action_out, float *best_score_out, int32_t *iters_out)
+{
+    if (action_out) std::memcpy(action_out, h->h_result, h->d.A * 4);
+    if (best_score_out) *best_score_out = h->h_result[32];
+    if (iters_out) *iters_out = reinterpret_cast<int32_t *>(h->h_result)[33];
+}
+
+}  // namespace
+
+extern "C" {
+
+int cem_plan_begin(cem_planner_t *h, const float *state, uint64_t seed, uint64_t call, const float *eps_act_dev, const float *eps_model_dev)
+{
+    if (!h || !state) return CEM_ERR_INVALID_ARG;
+    if (!h->have_weights) return CEM_ERR_NO_WEIGHTS;
+    if ((eps_act_dev == nullptr) != (eps_model_dev == nullptr) && h->cfg.sampling_propagation) return CEM_ERR_INVALID_ARG;
+    stage_ctrl(h, state, seed, call);
+    h->eps_act = eps_act_dev; h->eps_model = eps_model_dev;
+    h->ev_kind.clear();
+    int st = enqueue_begin(h); if (st) return st;
+    h->in_plan = true;
+    return CEM_OK;
+}
+
+int cem_plan_rollout(cem_planner_t *h, int32_t it)
+{
+    if (!h) return CEM_ERR_INVALID_ARG;
+    if (!h->in_plan) return CEM_ERR_STATE;
+    if (it < 0 || it >= h->d.I) return CEM_ERR_INVALID_ARG;
+    return enqueue_rollout(h, it);
+}
+
+int cem_plan_select(cem_planner_t *h, int32_t it)
+{
+    if (!h) return CEM_ERR_INVALID_ARG;
+    if (!h->in_plan) return CEM_ERR_STATE;
+    return enqueue_select(h, it);
+}
+
+int cem_plan_end(cem_planner_t *h, const float *eps_out_host, float *action_out, float *best_score_out, int32_t *iters_out)
+{
+    if (!h) return CEM_ERR_INVALID_ARG;
+    if (!h->in_plan) return CEM_ERR_STATE;
+    h->in_plan = false;
+    if (eps_out_host) HIPCHK(hipMemcpyAsync(h->ws + h->lay.eps_out, eps_out_host, h->d.A * 4, hipMemcpyHostToDevice, h->stream));
+    int st = enqueue_end(h, eps_out_host != nullptr); if (st) return st;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->timing) collect_timing(h);
+    read_result(h, action_out, best_score_out, iters_out);
+    return CEM_OK;
+}
+
+int cem_planner_plan(cem_planner_t *h, const float *state, uint64_t seed, uint64_t call, const float *eps_act_dev,
+                     const float *eps_model_dev, const float *eps_out_host, float *action_out, float *best_score_out, int32_t *iters_out)
+{
+    if (!h || !state) return CEM_ERR_INVALID_ARG;
+    if (!h->have_weights) return CEM_ERR_NO_WEIGHTS;
+    if (h->d.W != 1) return CEM_ERR_STATE;         // sharded ranks must use the stepwise calls around their collective
+    const bool graphable = h->cfg.use_graph && !eps_act_dev && !eps_model_dev && !eps_out_host && !h->timing;
+    if (graphable) {
+        stage_ctrl(h, state, seed, call);
+        if (!h->graph_ready) {
+            h->eps_act = h->eps_model = nullptr;
+            HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            int st = enqueue_begin(h);
+            for (int it = 0; it < h->d.I && !st; ++it) { st = enqueue_rollout(h, it); if (!st) st = enqueue_select(h, it); }
+            if (!st) st = enqueue_end(h, false);
+            hipError_t ce = hipStreamEndCapture(h->stream, &h->graph);
+            if (st) return st;
+            HIPCHK(ce);
+            HIPCHK(hipGraphInstantiate(&h->gexec, h->graph, nullptr, nullptr, 0));
+            h->graph_ready = true;
+        }
+        HIPCHK(hipGraphLaunch(h->gexec, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        read_result(h, action_out, best_score_out, iters_out);
+        return CEM_OK;
+    }
+    int st = cem_plan_begin(h, state, seed, call, eps_act_dev, eps_model_dev); if (st) return st;
+    for (int it = 0; it < h->d.I; ++it) {
+        st = cem_plan_rollout(h, it); if (st) return st;
+        st = cem_plan_select(h, it); if (st) return st;
+    }
+    return cem_plan_end(h, eps_out_host, action_out, best_score_out, iters_out);
+}
+
+int cem_unfold_sequences(cem_planner_t *h, const float *s0_dev, const float *actions_dev, int32_t n_rows, int32_t horizon,
+                         const float *eps_model_dev, uint64_t seed, uint64_t call, float *traj_out_dev, float *mu_out_dev, float *sd_out_dev)
+{
+    if (!h || !s0_dev || !actions_dev || n_rows < 1 || horizon < 1 || horizon > 65535) return CEM_ERR_INVALID_ARG;
+    if (!h->have_weights) return CEM_ERR_NO_WEIGHTS;
+    const Dims &d = h->d;
+    if (n_rows % d.E != 0) return CEM_ERR_SPLIT;
+    const int chunk = n_rows / d.E;
+    const int rc = n_rows >= 256 * 64 ? 4 : (n_rows >= 256 * 32 ? 2 : 1);
+    std::vector<Tile6> tiles;
+    for (int m = 0; m < d.E; ++m)
+        for (int r = m * chunk; r < (m + 1) * chunk; r += 16 * rc) {
+            Tile6 t; t.v[0] = r; t.v[1] = std::min(16 * rc, (m + 1) * chunk - r); t.v[2] = m; t.v[3] = r; t.v[4] = r; t.v[5] = r;
+            tiles.push_back(t);
+        }
+    TileDesc *dt = nullptr; float *ret = nullptr;
+    HIPCHK(hipMalloc((void **)&dt, tiles.size() * sizeof(Tile6)));
+    if (hipMalloc((void **)&ret, (size_t)n_rows * 4) != hipSuccess) { hipFree(dt); g_last_hip = (int)hipGetLastError(); return CEM_ERR_HIP; }
+    hipMemcpyAsync(dt, tiles.data(), tiles.size() * sizeof(Tile6), hipMemcpyHostToDevice, h->stream);
+    // Philox key for this call
+    CtrlBlock *c = h->h_ctrl;
+    c->seed_lo = (uint32_t)seed; c->seed_hi = (uint32_t)(seed >> 32); c->call_lo = (uint32_t)call; c->call_hi = (uint32_t)(call >> 32);
+    c->done = 0;
+    hipMemcpyAsync(h->ws + h->lay.ctrl, c, sizeof(CtrlBlock), hipMemcpyHostToDevice, h->stream);
+    RolloutParams rp; fill_rollout_common(h, rp);
+    rp.tiles = dt; rp.s0 = s0_dev; rp.actions = actions_dev; rp.eps_model = eps_model_dev; rp.ret = ret; rp.costs = nullptr;
+    rp.traj = traj_out_dev; rp.mu_out = mu_out_dev; rp.sd_out = sd_out_dev;
+    rp.H = horizon; rp.Bloc = n_rows; rp.Btot = n_rows; rp.it = 0; rp.variant = 0; rp.check_done = 0;
+    hipError_t e = launch_rollout<true>(rc, d.NFW, rp, (int)tiles.size(), h->stream);
+    hipError_t e2 = hipStreamSynchronize(h->stream);
+    hipFree(dt); hipFree(ret);
+    HIPCHK(e); HIPCHK(e2);
+    return CEM_OK;
+}
+
+int cem_fill_noise(cem_planner_t *h, uint64_t seed, uint64_t call, float *eps_act_dev, float *eps_model_dev, float *eps_out_dev)
+{
+    if (!h) return CEM_ERR_INVALID_ARG;
+    const Dims &d = h->d;
+    CtrlBlock *c = h->h_ctrl;
+    c->seed_lo = (uint32_t)seed; c->seed_hi = (uint32_t)(seed >> 32); c->call_lo = (uint32_t)call; c->call_hi = (uint32_t)(call >> 32);
+    HIPCHK(hipMemcpyAsync(h->ws + h->lay.ctrl, c, sizeof(CtrlBlock), hipMemcpyHostToDevice, h->stream));
+    FillParams fp{}; fp.eps_act = eps_act_dev; fp.eps_model = eps_model_dev; fp.eps_out = eps_out_dev;
+    fp.ctrl = (const CtrlBlock *)(h->ws + h->lay.ctrl); fp.I = d.I; fp.N = d.N; fp.H = d.H; fp.A = d.A; fp.B = d.Btot; fp.O = d.O;
+    hipLaunchKernelGGL(cem_fill_noise_kernel, dim3(2048), dim3(256), 0, h->stream, fp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CEM_OK;
+}
+
+int cem_planner_set_timing(cem_planner_t *h, int32_t enable)
+{
+    if (!h) return CEM_ERR_INVALID_ARG;
+    h->timing = enable != 0;
+    return CEM_OK;
+}
+
+int cem_planner_last_timing(cem_planner_t *h, float *rollout_ms_total, int32_t *rollout_launches, float *select_ms_total)
+{
+    if (!h) return CEM_ERR_INVALID_ARG;
+    if (rollout_ms_total) *rollout_ms_total = h->roll_ms;
+    if (rollout_launches) *rollout_launches = h->roll_n;
+    if (select_ms_total) *select_ms_total = h->sel_ms;
+    return CEM_OK;
+}
+
+}  // extern "C"

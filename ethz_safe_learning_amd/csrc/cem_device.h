@@ -1,0 +1,687 @@
+// cem_device.h — gfx950 (CDNA4) device code of the CEM-MPC planner.
+//
+// Kernels (one CEM iteration = sample -> rollout -> reduce -> select):
+//   cem_sample_kernel   cem_mpc.py:44-48        clip(eps*sigma+mu, lb, ub) -> actions[N][H][A]
+//   cem_rollout_kernel  cem_mpc.py:49-55        tile x P, unfold_sequences (transition_model.py:64-77) through
+//                                               the ensemble MLP (mlp_ensemble.py:59-61,122-132,189-193) and
+//                                               the reward/cost scorer (safety_gym.py:110-192) with the done
+//                                               masking of mpc_policy.py:26-37 / safe_cem_mpc.py:82-93, fused:
+//                                               traj[B][H+1][O] is never materialised.
+//   cem_reduce_kernel   mpc_policy.py:38-39, safe_cem_mpc.py:94-96,110-120   particle mean, Beta safety filter
+//   cem_select_kernel   cem_mpc.py:56-67        top_k, best-so-far, moments, smoothing, early stop
+//
+// Rollout kernel design: a workgroup of 4 waves owns a tile of 16*RC rows of ONE ensemble
+// member for the whole horizon.  Every dense layer is computed transposed, out^T[U x rows] = W^T . h^T, on
+// v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain): A = a 16-feature block of W^T, B = 16 rows of h^T.  In
+// that orientation the D layout of one layer (column = row of the batch on the lane, 4 consecutive output
+// features in the 4 accumulator registers) IS the B-operand layout of the next layer's k-step, so
+// activations move between layers as whole accumulator registers: each wave computes 32 of the 128 output
+// features, publishes them with 16-B LDS stores, and after one barrier every wave re-reads all 128 with
+// 16-B LDS loads, conflict-free, no shuffles, no transposes.  Weights are pre-packed on the host in
+// A-operand order per (member, wave) as one linear stream and prefetched L2 -> VGPR three groups ahead.
+// The state s_t lives in registers of the wave that owns its 16-feature block for all H steps.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+#define CEM_U 128            // hidden units (config/models.yaml:11)
+#define CEM_NG 8             // 16-feature blocks in U
+#define CEM_NKIND 5          // goal + up to 4 cost kinds
+#define CEM_PART_FLOATS (CEM_NKIND * 4 * 64)
+
+struct TileDesc {
+    int32_t row_base;        // local row index of slot 0 (index into returns/costs/traj)
+    int32_t cnt;             // valid rows in the tile (<= 16*RC)
+    int32_t member;          // ensemble member of every row of the tile (mlp_ensemble.py:123-126)
+    int32_t act_base;        // action-sequence index of slot 0
+    int32_t noise_row_base;  // GLOBAL row id of slot 0 (Philox counter / eps_model row): shard invariant
+    int32_t s0_base;         // -1: broadcast state (cem_mpc.py:53); else row index into s0[B][O]
+};
+
+struct CtrlBlock {
+    uint32_t seed_lo, seed_hi, call_lo, call_hi;
+    int32_t done;            // early stop reached (cem_mpc.py:66-67)
+    int32_t iters;           // iterations run
+    float best_score;        // best_so_far_score (cem_mpc.py:42)
+    int32_t pad;
+    float state[CEM_U];      // the observation (cem_mpc.py:32)
+    float best[32];          // best_so_far (cem_mpc.py:41)
+};
+
+struct ScorerDev {
+    int32_t goal_mode, goal_lo, goal_hi;
+    float D;                 // lidar_max_dist
+    float goal_thresh;       // fl32(goal_size * 0.8)  (safety_gym.py:116)
+    float reward_distance, reward_goal, reward_clip;
+    int32_t indicator, n_cost;
+    int32_t cost_lo[4], cost_hi[4];
+    float cost_size[4];
+};
+
+struct RolloutParams {
+    const TileDesc *tiles;
+    const f4 *wpack;             // packed weight streams [E][member_stride_f4]
+    const float *bias_h;         // [E][L][128]
+    const float *bias_mu;        // [E][128] zero padded
+    const float *bias_var;       // [E][128]
+    const float *nmin;           // [128] scale(): inputs_min, 0 on padding
+    const float *ndelta;         // [128] scale(): delta (1.01 rule applied), 1 on padding
+    const float *s0;             // [O] broadcast or [B][O]
+    const float *actions;        // [n_act][H][A]
+    const float *eps_model;      // nullptr -> Philox; else this iteration's [H][Btot][O]
+    const CtrlBlock *ctrl;
+    float *ret;                  // [Bloc] done-masked return per row
+    uint8_t *costs;              // [H][Bloc] masked cost per step (safe variant) or nullptr
+    float *traj, *mu_out, *sd_out;   // debug outputs (DEBUG instantiation only)
+    uint32_t member_stride_f4;
+    uint32_t wave_off_f4[4];
+    uint32_t wave_groups[4];
+    int32_t O, A, L, H, KB_in, KB_obs;
+    int32_t Bloc;
+    int32_t Btot;
+    int32_t it;
+    int32_t variant, sampling, check_done;
+    ScorerDev sc;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG (Salmon et al., SC'11) + Box-Muller.  Counter = (index, t | it<<16,
+// sub | stream<<16, call_lo), key = (seed_lo, seed_hi ^ call_hi): a pure function of GLOBAL indices, so
+// every rank of a candidate-sharded plan draws bit-identical noise for the same (candidate, particle).
+// ---------------------------------------------------------------------------------------------------------
+#define CEM_STREAM_MODEL 0u
+#define CEM_STREAM_ACT 1u
+#define CEM_STREAM_OUT 2u
+
+__device__ __forceinline__ void philox4x32_10(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__device__ __forceinline__ f4 cem_normal4(uint32_t idx, uint32_t t, uint32_t it, uint32_t sub, uint32_t stream, const CtrlBlock *ctrl)
+{
+    uint32_t c0 = idx, c1 = t | (it << 16), c2 = sub | (stream << 16), c3 = ctrl->call_lo;
+    philox4x32_10(c0, c1, c2, c3, ctrl->seed_lo, ctrl->seed_hi ^ ctrl->call_hi);
+    // 23-bit uniforms in (0,1): ((x>>9)+0.5) * 2^-23 is exact in fp32
+    const float u0 = ((float)(c0 >> 9) + 0.5f) * 1.1920928955078125e-07f;
+    const float u1 = ((float)(c1 >> 9) + 0.5f) * 1.1920928955078125e-07f;
+    const float u2 = ((float)(c2 >> 9) + 0.5f) * 1.1920928955078125e-07f;
+    const float u3 = ((float)(c3 >> 9) + 0.5f) * 1.1920928955078125e-07f;
+    // r = sqrt(-2 ln u) with v_log_f32 (log2); angle in revolutions for v_sin/v_cos
+    const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
+    const float rb = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
+    f4 z;
+    z[0] = ra * __builtin_amdgcn_cosf(u1);
+    z[1] = ra * __builtin_amdgcn_sinf(u1);
+    z[2] = rb * __builtin_amdgcn_cosf(u3);
+    z[3] = rb * __builtin_amdgcn_sinf(u3);
+    return z;
+}
+
+// tf.math.softplus as Eigen evaluates it
+__device__ __forceinline__ float cem_softplus(float x)
+{
+    const float thr = -13.942383766174316f;   // fl32(log(eps_f32) + 2)
+    if (x > -thr) return x;
+    const float ex = expf(x);
+    if (x < thr) return ex;
+    return log1pf(ex);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// rollout kernel
+// ---------------------------------------------------------------------------------------------------------
+struct AGroup { f4 a, b; };
+
+struct WQueue {              // 3-deep register prefetch queue over this wave's linear weight stream
+    const f4 *base;
+    int n, pos;
+    AGroup q0, q1, q2;
+    __device__ __forceinline__ AGroup ld(int g) const { AGroup r; r.a = base[g * 128]; r.b = base[g * 128 + 64]; return r; }
+    __device__ __forceinline__ void init(const f4 *b, int n_) { base = b; n = n_; q0 = ld(0); q1 = ld(1 % n_); q2 = ld(2 % n_); pos = 3 % n_; }
+    __device__ __forceinline__ AGroup pop() { AGroup r = q0; q0 = q1; q1 = q2; q2 = ld(pos); pos = (pos + 1 == n) ? 0 : pos + 1; return r; }
+};
+
+#define CEM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <int RC>
+__device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], const f4 (&hB)[CEM_NG][RC], WQueue &wq, const int kf)
+{
+#pragma unroll
+    for (int F = 0; F < CEM_NG; ++F) {
+        if (F < kf) {                       // wave-uniform
+            const AGroup g = wq.pop();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int c = 0; c < RC; ++c) {
+                    acc0[c] = CEM_MFMA(g.a[r], hB[F][c][r], acc0[c]);
+                    acc1[c] = CEM_MFMA(g.b[r], hB[F][c][r], acc1[c]);
+                }
+            }
+        }
+    }
+}
+
+template <int RC>
+__device__ __forceinline__ void cem_read_x(f4 (&hB)[CEM_NG][RC], const char *smem, const int xoff, const int lane, const int nblk)
+{
+#pragma unroll
+    for (int F = 0; F < CEM_NG; ++F) {
+        if (F < nblk) {
+#pragma unroll
+            for (int c = 0; c < RC; ++c)
+                hB[F][c] = *reinterpret_cast<const f4 *>(smem + xoff + ((c * CEM_NG + F) * 64 + lane) * 16);
+        }
+    }
+}
+
+template <int RC, int NFW, bool DEBUG>
+__global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.check_done && p.ctrl->done) return;
+
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const TileDesc td = p.tiles[blockIdx.x];
+    const int O = p.O, A = p.A, H = p.H;
+    constexpr int XB = RC * CEM_NG * 1024;
+    float *part = reinterpret_cast<float *>(smem + 2 * XB);
+    int xw = 0;                                          // buffer the next stage writes
+
+    WQueue wq;
+    wq.init(p.wpack + (size_t)td.member * p.member_stride_f4 + p.wave_off_f4[w] + lane, (int)p.wave_groups[w]);
+
+    const float *bias_h = p.bias_h + (size_t)td.member * p.L * CEM_U;
+    const float *bias_mu = p.bias_mu + (size_t)td.member * CEM_U;
+    const float *bias_var = p.bias_var + (size_t)td.member * CEM_U;
+
+    // ---- state registers: wave w owns input feature blocks Fo = w + 4 i --------------------------------
+    f4 s[NFW][RC];
+    int slotc[RC];
+#pragma unroll
+    for (int c = 0; c < RC; ++c) { const int sl = 16 * c + j; slotc[c] = sl < td.cnt ? sl : td.cnt - 1; }
+#pragma unroll
+    for (int i = 0; i < NFW; ++i) {
+        const int f0 = 16 * (w + 4 * i) + 4 * q;
+#pragma unroll
+        for (int c = 0; c < RC; ++c) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = f0 + r;
+                float v = 0.f;
+                if (f < O) v = td.s0_base < 0 ? p.ctrl->state[f] : p.s0[(size_t)(td.s0_base + slotc[c]) * O + f];
+                s[i][c][r] = v;
+            }
+        }
+    }
+
+    // score owner (wave 0, lane == row slot)
+    float d_prev = 0.f, c_prev = 0.f, cum = 0.f;
+    bool done = false;
+    const int nk = 1 + p.sc.n_cost;
+
+    f4 hB[CEM_NG][RC];
+
+    for (int t = -1; t < H; ++t) {
+        if (t >= 0) {
+            // ---- hidden layers: h = relu(h W + b)  (mlp_ensemble.py:18-22) -----------------------------
+            for (int l = 0; l < p.L; ++l) {
+                f4 acc0[RC], acc1[RC];
+#pragma unroll
+                for (int c = 0; c < RC; ++c) { acc0[c] = (f4){0.f, 0.f, 0.f, 0.f}; acc1[c] = (f4){0.f, 0.f, 0.f, 0.f}; }
+                const f4 b0 = *reinterpret_cast<const f4 *>(bias_h + l * CEM_U + 16 * (2 * w) + 4 * q);
+                const f4 b1 = *reinterpret_cast<const f4 *>(bias_h + l * CEM_U + 16 * (2 * w + 1) + 4 * q);
+                if (l == 0) cem_mfma_stage<RC>(acc0, acc1, hB, wq, p.KB_in);
+                else cem_mfma_stage<RC>(acc0, acc1, hB, wq, CEM_NG);
+#pragma unroll
+                for (int c = 0; c < RC; ++c) {
+                    f4 h0 = acc0[c] + b0, h1 = acc1[c] + b1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { h0[r] = fmaxf(h0[r], 0.f); h1[r] = fmaxf(h1[r], 0.f); }
+                    *reinterpret_cast<f4 *>(smem + xw + ((c * CEM_NG + 2 * w) * 64 + lane) * 16) = h0;
+                    *reinterpret_cast<f4 *>(smem + xw + ((c * CEM_NG + 2 * w + 1) * 64 + lane) * 16) = h1;
+                }
+                __syncthreads();
+                cem_read_x<RC>(hB, smem, xw, lane, CEM_NG);
+                xw ^= XB;
+            }
+        }
+
+        // ---- heads (mlp_ensemble.py:33-34,189-193), state update (transition_model.py:75), scorer
+        //      partials (safety_gym.py:188-192) and the next scaled input (transition_model.py:70-72,79-87)
+        float pm[CEM_NKIND][RC];
+#pragma unroll
+        for (int k = 0; k < CEM_NKIND; ++k)
+#pragma unroll
+            for (int c = 0; c < RC; ++c) pm[k][c] = __builtin_inff();
+        const int tn = (t + 1 < H) ? t + 1 : H - 1;
+
+#pragma unroll
+        for (int i = 0; i < NFW; ++i) {
+            const int Fo = w + 4 * i;
+            if (Fo < p.KB_in) {
+                const bool heads = (t >= 0) && (Fo < p.KB_obs);
+                const int f0 = 16 * Fo + 4 * q;
+                const f4 mn4 = *reinterpret_cast<const f4 *>(p.nmin + f0);
+                const f4 dl4 = *reinterpret_cast<const f4 *>(p.ndelta + f0);
+                f4 accm[RC], accv[RC];
+#pragma unroll
+                for (int c = 0; c < RC; ++c) { accm[c] = (f4){0.f, 0.f, 0.f, 0.f}; accv[c] = (f4){0.f, 0.f, 0.f, 0.f}; }
+                f4 bm = (f4){0.f, 0.f, 0.f, 0.f}, bv = (f4){0.f, 0.f, 0.f, 0.f};
+                if (heads) {
+                    bm = *reinterpret_cast<const f4 *>(bias_mu + f0);
+                    bv = *reinterpret_cast<const f4 *>(bias_var + f0);
+                    cem_mfma_stage<RC>(accm, accv, hB, wq, CEM_NG);
+                }
+#pragma unroll
+                for (int c = 0; c < RC; ++c) {
+                    const int slot = 16 * c + j;
+                    const bool valid = slot < td.cnt;
+                    f4 sn = s[i][c];
+                    if (heads) {
+                        f4 eps = (f4){0.f, 0.f, 0.f, 0.f};
+                        if (p.sampling) {
+                            if (p.eps_model) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    if (f0 + r < O) eps[r] = p.eps_model[((size_t)t * p.Btot + td.noise_row_base + slotc[c]) * O + f0 + r];
+                            } else {
+                                eps = cem_normal4((uint32_t)(td.noise_row_base + slotc[c]), (uint32_t)t, (uint32_t)p.it, (uint32_t)(4 * Fo + q), CEM_STREAM_MODEL, p.ctrl);
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int f = f0 + r;
+                            const float mu = accm[c][r] + bm[r];
+                            const float var = cem_softplus(accv[c][r] + bv[r]) + 1e-4f;
+                            const float sd = sqrtf(var);
+                            const float d = p.sampling ? mu + sd * eps[r] : mu;      // Normal.sample = loc + scale*eps
+                            if (f < O) sn[r] = sn[r] + d;                            // s_t += d_s_t
+                            if (DEBUG) {
+                                if (valid && f < O) {
+                                    const size_t o = ((size_t)(td.row_base + slot) * H + t) * O + f;
+                                    if (p.mu_out) p.mu_out[o] = mu;
+                                    if (p.sd_out) p.sd_out[o] = sd;
+                                }
+                            }
+                        }
+                        s[i][c] = sn;
+                    }
+                    if (DEBUG) {
+                        if (p.traj && valid) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (f0 + r < O) p.traj[((size_t)(td.row_base + slot) * (H + 1) + (t + 1)) * O + f0 + r] = sn[r];
+                        }
+                    }
+                    // closest_distance terms of the lidar features this lane holds
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int f = f0 + r;
+                        const float lid = fminf(fmaxf(p.sc.D - p.sc.D * (1.0f - sn[r]), 0.f), p.sc.D);
+                        const float gv = p.sc.goal_mode ? fmaxf(sn[r], 0.f) : lid;
+                        const bool ing = p.sc.goal_mode ? (f == p.sc.goal_lo) : (f >= p.sc.goal_lo && f < p.sc.goal_hi);
+                        pm[0][c] = ing ? fminf(pm[0][c], gv) : pm[0][c];
+#pragma unroll
+                        for (int k = 1; k < CEM_NKIND; ++k) {
+                            if (k < nk) {
+                                const bool in = f >= p.sc.cost_lo[k - 1] && f < p.sc.cost_hi[k - 1];
+                                pm[k][c] = in ? fminf(pm[k][c], lid) : pm[k][c];
+                            }
+                        }
+                    }
+                    // next scaled input x = (concat[s, a] - min) / delta
+                    f4 x;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int f = f0 + r;
+                        float xv = 0.f;
+                        if (f < O) xv = sn[r];
+                        else if (f < O + A) xv = p.actions[((size_t)(td.act_base + slotc[c]) * H + tn) * A + (f - O)];
+                        x[r] = (xv - mn4[r]) / dl4[r];
+                    }
+                    *reinterpret_cast<f4 *>(smem + xw + ((c * CEM_NG + Fo) * 64 + lane) * 16) = x;
+                }
+            }
+        }
+        // wave-level min over the 4 lane groups that hold different features of the same row
+#pragma unroll
+        for (int k = 0; k < CEM_NKIND; ++k) {
+            if (k < nk) {
+#pragma unroll
+                for (int c = 0; c < RC; ++c) {
+                    float m = pm[k][c];
+                    m = fminf(m, __shfl_xor(m, 16));
+                    m = fminf(m, __shfl_xor(m, 32));
+                    if (q == 0) part[(k * 4 + w) * 64 + 16 * c + j] = m;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- reward / cost / done bookkeeping of step t (rows of the tile on wave 0's lanes) ------------
+        if (w == 0) {
+            float dn = fminf(fminf(part[0 * 64 + lane], part[1 * 64 + lane]), fminf(part[2 * 64 + lane], part[3 * 64 + lane]));
+            float cn = 0.f;
+            for (int k = 1; k < nk; ++k) {
+                const float dk = fminf(fminf(part[(k * 4 + 0) * 64 + lane], part[(k * 4 + 1) * 64 + lane]),
+                                       fminf(part[(k * 4 + 2) * 64 + lane], part[(k * 4 + 3) * 64 + lane]));
+                cn = cn + ((dk <= p.sc.cost_size[k - 1]) ? 1.0f : 0.0f);
+            }
+            if (p.sc.indicator) cn = cn > 0.f ? 1.0f : 0.0f;
+            if (t >= 0) {
+                const bool ga = d_prev <= p.sc.goal_thresh;                                   // safety_gym.py:116
+                float r = (d_prev - dn) * p.sc.reward_distance + (ga ? 1.0f : 0.0f) * p.sc.reward_goal;
+                if (p.sc.reward_clip > 0.f) r = fminf(fmaxf(r, -p.sc.reward_clip), p.sc.reward_clip);
+                if (p.variant == 1) {                                                         // safe_cem_mpc.py:86-93
+                    done = done || ga;
+                    const float nd = done ? 0.0f : 1.0f;
+                    const float cst = c_prev * nd;
+                    if (p.costs && lane < td.cnt) p.costs[(size_t)t * p.Bloc + td.row_base + lane] = (uint8_t)cst;
+                    cum = cum + r * nd;
+                } else {                                                                      // mpc_policy.py:34-37
+                    const float nd = done ? 0.0f : 1.0f;
+                    cum = cum + r * nd;
+                    done = done || ga;
+                }
+            }
+            d_prev = dn;
+            c_prev = cn;
+        }
+        cem_read_x<RC>(hB, smem, xw, lane, p.KB_in);
+        xw ^= XB;
+    }
+    if (w == 0 && lane < td.cnt) p.ret[td.row_base + lane] = cum;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// small kernels of the optimiser loop
+// ---------------------------------------------------------------------------------------------------------
+struct InitParams { CtrlBlock *ctrl; float *musig; int32_t HA, A; float mu0[32], sigma0[32]; };
+
+__global__ void cem_init_kernel(const InitParams p)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < p.HA) { p.musig[i] = p.mu0[i % p.A]; p.musig[p.HA + i] = p.sigma0[i % p.A]; }   // cem_mpc.py:39-40
+    if (i < 32) p.ctrl->best[i] = 0.f;                                                         // cem_mpc.py:41
+    if (i == 0) { p.ctrl->best_score = -__builtin_inff(); p.ctrl->done = 0; p.ctrl->iters = 0; }
+}
+
+struct SampleParams {
+    float *actions; const float *musig; const float *eps_act; const CtrlBlock *ctrl;
+    int32_t N, H, A, it, check_done;
+    float lb[32], ub[32];
+};
+
+__global__ __launch_bounds__(256) void cem_sample_kernel(const SampleParams p)
+{
+    if (p.check_done && p.ctrl->done) return;
+    const int AZ = (p.A + 3) >> 2;
+    const int total = p.N * p.H * AZ;
+    const int HA = p.H * p.A;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int z = idx % AZ, t = (idx / AZ) % p.H, n = idx / (AZ * p.H);
+        f4 e = (f4){0.f, 0.f, 0.f, 0.f};
+        if (!p.eps_act) e = cem_normal4((uint32_t)n, (uint32_t)t, (uint32_t)p.it, (uint32_t)z, CEM_STREAM_ACT, p.ctrl);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = 4 * z + r;
+            if (a < p.A) {
+                const float eps = p.eps_act ? p.eps_act[((size_t)n * p.H + t) * p.A + a] : e[r];
+                float v = eps * p.musig[HA + t * p.A + a] + p.musig[t * p.A + a];          // tf.random.normal(mean, stddev)
+                v = fminf(fmaxf(v, p.lb[a]), p.ub[a]);                                      // tf.clip_by_value
+                p.actions[((size_t)n * p.H + t) * p.A + a] = v;
+            }
+        }
+    }
+}
+
+struct ReduceParams {
+    const float *ret; const uint8_t *costs; float *scores; const CtrlBlock *ctrl;
+    int32_t Nloc, P, H, variant, check_done;
+    float alpha, beta, thr;
+};
+
+__global__ __launch_bounds__(256) void cem_reduce_kernel(const ReduceParams p)
+{
+    if (p.check_done && p.ctrl->done) return;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= p.Nloc) return;
+    float sum = 0.f;
+    for (int q = 0; q < p.P; ++q) sum = sum + p.ret[(size_t)q * p.Nloc + n];
+    float score = sum / (float)p.P;                                    // reduce_mean over particles
+    if (p.variant == 1) {                                              // safe_cem_mpc.py:90-96,110-120
+        bool safe = true;
+        const float denom = (p.alpha + p.beta) + (float)p.P;
+        const size_t Bloc = (size_t)p.P * p.Nloc;
+        for (int t = 0; t < p.H; ++t) {
+            float cnt = 0.f;
+            for (int q = 0; q < p.P; ++q) cnt = cnt + (float)p.costs[(size_t)t * Bloc + (size_t)q * p.Nloc + n];
+            const float post = (p.alpha + cnt) / denom;
+            safe = safe && (post <= p.thr);
+        }
+        score = score - (safe ? 0.0f : 1.0f) * 100.0f;
+    }
+    p.scores[n] = score;
+}
+
+struct SelectParams {
+    const float *scores; const float *actions; float *musig; CtrlBlock *ctrl; int32_t *elite_idx;
+    int32_t N, k, HA, A, check_done;
+    float smoothing, threshold;
+};
+
+__device__ __forceinline__ uint32_t cem_f2key(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    if (f != f) return 0u;                                   // NaN sorts lowest
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// exclusive scan of one value per thread over a 1024-thread block; returns exclusive prefix, total via ref
+__device__ __forceinline__ uint32_t cem_block_excl_scan(uint32_t v, uint32_t *wsum /*[17]*/, uint32_t &total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+    __syncthreads();
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int i = 0; i < 16; ++i) { const uint32_t x = wsum[i]; wsum[i] = run; run += x; } wsum[16] = run; }
+    __syncthreads();
+    total = wsum[16];
+    return wsum[wv] + inc - v;
+}
+
+// top_k + best-so-far + moments + smoothing + early stop, one 1024-thread workgroup  (cem_mpc.py:56-67)
+__global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char sel_smem[];
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t wsum[17];
+    __shared__ uint32_t sh_prefix, sh_need;
+    __shared__ float red[1024];
+    __shared__ float bsc[16];
+    __shared__ int bpos[16];
+    if (p.check_done && p.ctrl->done) return;
+
+    int32_t *elite = reinterpret_cast<int32_t *>(sel_smem);                 // [k]
+    float *colmean = reinterpret_cast<float *>(sel_smem + (size_t)((p.k + 3) & ~3) * 4);   // [HA]
+    const int tid = threadIdx.x;
+    const int N = p.N, k = p.k;
+
+    // ---- radix select of the k-th largest key ----------------------------------------------------------
+    uint32_t prefix = 0, mask = 0, need = (uint32_t)k;
+    for (int pass = 3; pass >= 0; --pass) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < N; i += 1024) {
+            const uint32_t key = cem_f2key(p.scores[i]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> (8 * pass)) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t run = 0; int b = 255;
+            for (; b > 0; --b) { if (run + hist[b] >= need) break; run += hist[b]; }
+            sh_prefix = prefix | ((uint32_t)b << (8 * pass));
+            sh_need = need - run;
+        }
+        __syncthreads();
+        prefix = sh_prefix; need = sh_need; mask |= 0xFFu << (8 * pass);
+        __syncthreads();
+    }
+    const uint32_t T = prefix;          // key of the k-th largest score; `need` ties are taken, lowest index first
+
+    // ---- compaction in ascending candidate index (tf.nn.top_k ties -> lower index) -------------------------
+    const int C = (N + 1023) / 1024;
+    const int beg = tid * C, end = (beg + C < N) ? beg + C : N;
+    uint32_t ngt = 0, neq = 0;
+    for (int i = beg; i < end; ++i) { const uint32_t key = cem_f2key(p.scores[i]); ngt += key > T; neq += key == T; }
+    uint32_t tot_gt, tot_eq;
+    const uint32_t pre_gt = cem_block_excl_scan(ngt, wsum, tot_gt);
+    const uint32_t pre_eq = cem_block_excl_scan(neq, wsum, tot_eq);
+    {
+        uint32_t eqr = pre_eq;
+        uint32_t pos = pre_gt + (pre_eq < need ? pre_eq : need);
+        for (int i = beg; i < end; ++i) {
+            const uint32_t key = cem_f2key(p.scores[i]);
+            bool take = key > T;
+            if (key == T) { take = eqr < need; ++eqr; }
+            if (take) { elite[pos] = i; p.elite_idx[pos] = i; ++pos; }
+        }
+    }
+    __syncthreads();
+
+    // ---- best of elite: max score, first (= lowest index) among exact ties  (cem_mpc.py:57-60) -------------
+    {
+        float bs = -__builtin_inff(); int bp = 0x7fffffff;
+        for (int e = tid; e < k; e += 1024) {
+            const float sc = p.scores[elite[e]];
+            if (bp == 0x7fffffff || sc > bs) { bs = sc; bp = e; }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float os = __shfl_xor(bs, d); const int op = __shfl_xor(bp, d);
+            if (op != 0x7fffffff && (bp == 0x7fffffff || os > bs || (os == bs && op < bp))) { bs = os; bp = op; }
+        }
+        if ((tid & 63) == 0) { bsc[tid >> 6] = bs; bpos[tid >> 6] = bp; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 1; i < 16; ++i) {
+                const float os = bsc[i]; const int op = bpos[i];
+                if (op != 0x7fffffff && (bp == 0x7fffffff || os > bs || (os == bs && op < bp))) { bs = os; bp = op; }
+            }
+            if (bs > p.ctrl->best_score) {                                   // strict (cem_mpc.py:58)
+                const int idx = elite[bp];
+                for (int a = 0; a < p.A; ++a) p.ctrl->best[a] = p.actions[(size_t)idx * p.HA + a];   // first step's action
+                p.ctrl->best_score = bs;
+            }
+        }
+    }
+
+    // ---- moments over the elite set (tf.nn.moments: mean, then mean squared difference) ---------------------
+    const float fk = (float)k;
+    const float sm = p.smoothing;
+    for (int cb = 0; cb < p.HA; cb += 1024) {
+        const int ncol = (p.HA - cb < 1024) ? p.HA - cb : 1024;
+        int tpc = 1; while (tpc * 2 * ncol <= 1024) tpc *= 2;
+        const int part = tid / ncol, col = tid % ncol;
+        const bool act = part < tpc;
+        for (int phase = 0; phase < 2; ++phase) {
+            float acc = 0.f;
+            const float m = phase ? colmean[cb + col] : 0.f;
+            if (act) {
+                for (int e = part; e < k; e += tpc) {
+                    const float a = p.actions[(size_t)elite[e] * p.HA + cb + col];
+                    acc = phase ? acc + (a - m) * (a - m) : acc + a;
+                }
+            }
+            __syncthreads();
+            red[tid] = acc;
+            __syncthreads();
+            if (part == 0) {
+                float tot = 0.f;
+                for (int pp = 0; pp < tpc; ++pp) tot = tot + red[pp * ncol + col];
+                if (!phase) colmean[cb + col] = tot / fk;
+                else {
+                    const float sd = sqrtf(tot / fk);
+                    const int ci = cb + col;
+                    p.musig[ci] = sm * p.musig[ci] + (1.0f - sm) * colmean[ci];              // cem_mpc.py:64
+                    p.musig[p.HA + ci] = sm * p.musig[p.HA + ci] + (1.0f - sm) * sd;          // cem_mpc.py:65
+                }
+            }
+            __syncthreads();
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) {
+        float ssum = 0.f;
+        for (int i = 0; i < p.HA; ++i) ssum = ssum + p.musig[p.HA + i];
+        const float mean_sigma = ssum / (float)p.HA;
+        p.ctrl->iters = p.ctrl->iters + 1;
+        if (mean_sigma <= p.threshold) p.ctrl->done = 1;                                      // cem_mpc.py:66-67
+    }
+}
+
+struct FinalParams { const CtrlBlock *ctrl; const float *eps_out; float *result; int32_t A; float noise_stddev; };
+
+__global__ void cem_final_kernel(const FinalParams p)
+{
+    const int a = threadIdx.x;
+    if (a < p.A) {
+        float eps;
+        if (p.eps_out) eps = p.eps_out[a];
+        else { const f4 e = cem_normal4((uint32_t)(a >> 2), 0u, 0u, 0u, CEM_STREAM_OUT, p.ctrl); eps = e[a & 3]; }
+        p.result[a] = p.ctrl->best[a] + eps * p.noise_stddev;                                 // cem_mpc.py:68
+    }
+    if (a == 0) {
+        p.result[32] = p.ctrl->best_score;
+        reinterpret_cast<int32_t *>(p.result)[33] = p.ctrl->iters;
+        reinterpret_cast<int32_t *>(p.result)[34] = p.ctrl->done;
+    }
+}
+
+struct FillParams { float *eps_act, *eps_model, *eps_out; const CtrlBlock *ctrl; int32_t I, N, H, A, B, O; };
+
+// dump the Philox streams in the explicit-tensor layouts (parity mode inputs)
+__global__ __launch_bounds__(256) void cem_fill_noise_kernel(const FillParams p)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (size_t)gridDim.x * blockDim.x;
+    if (p.eps_act) {
+        const int AZ = (p.A + 3) >> 2;
+        const size_t total = (size_t)p.I * p.N * p.H * AZ;
+        for (size_t idx = gid; idx < total; idx += gsz) {
+            const int z = idx % AZ, t = (idx / AZ) % p.H, n = (idx / ((size_t)AZ * p.H)) % p.N, it = idx / ((size_t)AZ * p.H * p.N);
+            const f4 e = cem_normal4((uint32_t)n, (uint32_t)t, (uint32_t)it, (uint32_t)z, CEM_STREAM_ACT, p.ctrl);
+            for (int r = 0; r < 4; ++r) if (4 * z + r < p.A) p.eps_act[(((size_t)it * p.N + n) * p.H + t) * p.A + 4 * z + r] = e[r];
+        }
+    }
+    if (p.eps_model) {
+        const int OZ = (p.O + 3) >> 2;
+        const size_t total = (size_t)p.I * p.H * p.B * OZ;
+        for (size_t idx = gid; idx < total; idx += gsz) {
+            const int fq = idx % OZ; const size_t row = (idx / OZ) % p.B; const int t = (idx / ((size_t)OZ * p.B)) % p.H, it = idx / ((size_t)OZ * p.B * p.H);
+            const f4 e = cem_normal4((uint32_t)row, (uint32_t)t, (uint32_t)it, (uint32_t)fq, CEM_STREAM_MODEL, p.ctrl);
+            for (int r = 0; r < 4; ++r) if (4 * fq + r < p.O) p.eps_model[(((size_t)it * p.H + t) * p.B + row) * p.O + 4 * fq + r] = e[r];
+        }
+    }
+    if (p.eps_out && gid < (size_t)p.A) {
+        const f4 e = cem_normal4((uint32_t)(gid >> 2), 0u, 0u, 0u, CEM_STREAM_OUT, p.ctrl);
+        p.eps_out[gid] = e[gid & 3];
+    }
+}

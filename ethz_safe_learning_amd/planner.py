@@ -1,0 +1,344 @@
+"""Thin Python host over the C ABI: device memory and streams come from
+torch-ROCm (plumbing), every computation happens in libcem_mpc_gfx950.so.
+
+``CemPlanner`` is what the simba-shaped policies (``simba/policies``) hold; it
+corresponds to one compiled ``@tf.function`` graph of the reference
+(simba/policies/cem_mpc.py:35) for one set of shapes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _capi
+
+
+@dataclass
+class ScorerConfig:
+    """SafetyGymStateScorer fields for the 'goal' task
+    (reference simba/environment_utils/safety_gym.py:104-176)."""
+    goal_slice: Tuple[int, int]
+    observe_goal_lidar: bool = True
+    lidar_max_dist: float = 4.0
+    goal_size: float = 0.3
+    reward_distance: float = 1.0
+    reward_goal: float = 1.0
+    reward_clip: float = 10.0
+    constrain_indicator: bool = True
+    cost_kinds: List[Tuple[int, int, float]] = field(default_factory=list)   # (lo, hi, size), reference order
+
+
+@dataclass
+class PlannerConfig:
+    """CemMpc/SafeCemMpc ctor kwargs (cem_mpc.py:7-17, safe_cem_mpc.py:8-19) +
+    model dims (config/models.yaml) + sharding."""
+    obs_dim: int
+    act_dim: int
+    ensemble_size: int
+    particles: int
+    n_samples: int
+    horizon: int
+    n_elite: int
+    iterations: int
+    scorer: ScorerConfig
+    act_low: Sequence[float]
+    act_high: Sequence[float]
+    units: int = 128
+    n_layers: int = 4
+    smoothing: float = 0.0
+    stddev_threshold: float = -1.0
+    noise_stddev: float = 0.0
+    variant: str = 'cem'
+    posterior_mean_threashold: float = 0.15
+    sampling_propagation: bool = True
+    scale_features: bool = True
+    world_size: int = 1
+    rank: int = 0
+    chunks_per_tile: int = 0
+    use_graph: bool = False
+
+
+def sampling_params(low, high):
+    """MpcPolicy.sampling_params (reference simba/policies/mpc_policy.py:45-57)."""
+    low = np.asarray(low, np.float32)
+    high = np.asarray(high, np.float32)
+    if np.all(np.isfinite(low)) and np.all(np.isfinite(high)):
+        return low, high, (high + low) / np.float32(2.0), (high - low) / np.float32(2.0)
+    a = low.shape[0]
+    return (np.full(a, -100, np.float32), np.full(a, 100, np.float32), np.zeros(a, np.float32),
+            np.full(a, 100, np.float32))
+
+
+def to_c_config(cfg: PlannerConfig) -> _capi.CemConfig:
+    c = _capi.CemConfig()
+    c.abi_version = _capi.CEM_ABI_VERSION
+    c.obs_dim, c.act_dim, c.units, c.n_layers = cfg.obs_dim, cfg.act_dim, cfg.units, cfg.n_layers
+    c.ensemble_size, c.particles, c.n_samples = cfg.ensemble_size, cfg.particles, cfg.n_samples
+    c.horizon, c.n_elite, c.iterations = cfg.horizon, cfg.n_elite, cfg.iterations
+    c.smoothing, c.stddev_threshold, c.noise_stddev = cfg.smoothing, cfg.stddev_threshold, cfg.noise_stddev
+    if cfg.variant not in ('cem', 'safe'):
+        raise ValueError("variant must be 'cem' or 'safe'")
+    c.variant = 1 if cfg.variant == 'safe' else 0
+    c.posterior_mean_threashold = cfg.posterior_mean_threashold
+    c.sampling_propagation = int(bool(cfg.sampling_propagation))
+    c.scale_features = int(bool(cfg.scale_features))
+    if cfg.act_dim > _capi.CEM_MAX_ACT:
+        raise ValueError('act_dim > %d' % _capi.CEM_MAX_ACT)
+    lb, ub, mu0, sg0 = sampling_params(cfg.act_low, cfg.act_high)
+    if lb.shape != (cfg.act_dim,):
+        raise ValueError('act_low/act_high must have shape [act_dim]')
+    for a in range(cfg.act_dim):
+        c.act_lb[a], c.act_ub[a], c.act_mu0[a], c.act_sigma0[a] = float(lb[a]), float(ub[a]), float(mu0[a]), float(sg0[a])
+    s = cfg.scorer
+    c.scorer.goal_mode = 0 if s.observe_goal_lidar else 1
+    c.scorer.goal_lo, c.scorer.goal_hi = int(s.goal_slice[0]), int(s.goal_slice[1])
+    c.scorer.lidar_max_dist, c.scorer.goal_size = s.lidar_max_dist, s.goal_size
+    c.scorer.reward_distance, c.scorer.reward_goal = s.reward_distance, s.reward_goal
+    c.scorer.reward_clip = float(s.reward_clip) if s.reward_clip else 0.0
+    c.scorer.constrain_indicator = int(bool(s.constrain_indicator))
+    if len(s.cost_kinds) > _capi.CEM_MAX_COST_KINDS:
+        raise ValueError('too many cost kinds')
+    c.scorer.n_cost_kinds = len(s.cost_kinds)
+    for i, (lo, hi, size) in enumerate(s.cost_kinds):
+        c.scorer.cost_lo[i], c.scorer.cost_hi[i], c.scorer.cost_size[i] = int(lo), int(hi), float(size)
+    c.world_size, c.rank, c.chunks_per_tile, c.use_graph = cfg.world_size, cfg.rank, cfg.chunks_per_tile, int(cfg.use_graph)
+    return c
+
+
+def flatten_weights(weights) -> np.ndarray:
+    """Keras-layout per-member weights -> the natural blob of cem_mpc.h:
+    W_0,b_0,...,W_{L-1},b_{L-1},W_mu,b_mu,W_var,b_var per member, [in][out] row-major."""
+    parts = []
+    for w in weights:
+        for W, b in zip(w['W'], w['b']):
+            parts += [np.asarray(W, np.float32).ravel(), np.asarray(b, np.float32).ravel()]
+        parts += [np.asarray(w['W_mu'], np.float32).ravel(), np.asarray(w['b_mu'], np.float32).ravel(),
+                  np.asarray(w['W_var'], np.float32).ravel(), np.asarray(w['b_var'], np.float32).ravel()]
+    return np.ascontiguousarray(np.concatenate(parts))
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class CemPlanner:
+    """One planner handle (fixed shapes) on one GPU."""
+
+    def __init__(self, cfg: PlannerConfig, device='cuda:0'):
+        import torch
+        self._torch = torch
+        self.lib = _capi.load()                       # raises if the HIP extension is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError('CemPlanner needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path')
+        self.cfg = cfg
+        self.ccfg = to_c_config(cfg)
+        self.device = torch.device(device)
+        nbytes = self.lib.cem_workspace_bytes(C.byref(self.ccfg))
+        if nbytes == 0:
+            # let create() report the precise status
+            nbytes = 256
+        with torch.cuda.device(self.device):
+            self.workspace = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.device)
+            off = (-self.workspace.data_ptr()) % 256
+            self._ws_view = self.workspace[off:off + nbytes]
+            self.stream = torch.cuda.current_stream(self.device)
+            h = C.c_void_p()
+            _capi.check(self.lib.cem_planner_create(C.byref(self.ccfg), _ptr(self._ws_view), nbytes,
+                                                    C.c_void_p(self.stream.cuda_stream), C.byref(h)), 'cem_planner_create')
+        self.h = h
+        lay = _capi.CemLayout()
+        _capi.check(self.lib.cem_planner_layout(self.h, C.byref(lay)), 'cem_planner_layout')
+        self.layout = lay
+        self._call = 0
+
+    # ------------------------------------------------------------------ views
+    def _view(self, off, count, dtype):
+        t = self._torch
+        nb = count * t.tensor([], dtype=dtype).element_size()
+        return self._ws_view[off:off + nb].view(dtype)
+
+    @property
+    def n_local(self):
+        return self.cfg.n_samples // self.cfg.world_size
+
+    def scores_local(self):
+        return self._view(self.layout.scores_local, self.n_local, self._torch.float32)
+
+    def scores_global(self):
+        return self._view(self.layout.scores_global, self.cfg.n_samples, self._torch.float32)
+
+    def actions(self):
+        c = self.cfg
+        return self._view(self.layout.actions, c.n_samples * c.horizon * c.act_dim, self._torch.float32).view(
+            c.n_samples, c.horizon, c.act_dim)
+
+    def mu_sigma(self):
+        c = self.cfg
+        return self._view(self.layout.mu_sigma, 2 * c.horizon * c.act_dim, self._torch.float32).view(2, c.horizon, c.act_dim)
+
+    def elite_idx(self):
+        return self._view(self.layout.elite_idx, self.cfg.n_elite, self._torch.int32)
+
+    def returns(self):
+        c = self.cfg
+        return self._view(self.layout.returns, c.particles * self.n_local, self._torch.float32).view(c.particles, self.n_local)
+
+    def costs(self):
+        c = self.cfg
+        return self._view(self.layout.costs, c.horizon * c.particles * self.n_local, self._torch.uint8).view(
+            c.horizon, c.particles, self.n_local)
+
+    # ------------------------------------------------------------------ sync hooks
+    def set_weights(self, weights):
+        blob = flatten_weights(weights)
+        expect = self.lib.cem_weight_blob_floats(C.byref(self.ccfg))
+        if blob.size != expect:
+            raise ValueError('weight blob has %d floats, expected %d' % (blob.size, expect))
+        _capi.check(self.lib.cem_planner_set_weights(self.h, _np_ptr(blob), blob.size), 'cem_planner_set_weights')
+
+    def set_normaliser(self, inputs_min, inputs_max):
+        mn = np.ascontiguousarray(np.asarray(inputs_min, np.float32))
+        mx = np.ascontiguousarray(np.asarray(inputs_max, np.float32))
+        if mn.shape != (self.cfg.obs_dim + self.cfg.act_dim,) or mx.shape != mn.shape:
+            raise ValueError('normaliser must have shape [obs_dim + act_dim]')
+        _capi.check(self.lib.cem_planner_set_normaliser(self.h, _np_ptr(mn), _np_ptr(mx)), 'cem_planner_set_normaliser')
+
+    # ------------------------------------------------------------------ planning
+    def _noise_args(self, eps_act, eps_model):
+        c = self.cfg
+        t = self._torch
+        if eps_act is None and eps_model is None:
+            return None, None
+        if eps_act is None or eps_model is None:
+            raise ValueError('eps_act and eps_model must be given together')
+        B = c.particles * c.n_samples
+        ea = t.as_tensor(eps_act, dtype=t.float32, device=self.device).contiguous()
+        em = t.as_tensor(eps_model, dtype=t.float32, device=self.device).contiguous()
+        if tuple(ea.shape) != (c.iterations, c.n_samples, c.horizon, c.act_dim):
+            raise ValueError('eps_act must be [I,N,H,A]')
+        if tuple(em.shape) != (c.iterations, c.horizon, B, c.obs_dim):
+            raise ValueError('eps_model must be [I,H,P*N,O]')
+        return ea, em
+
+    def plan(self, state, seed=0, call=None, eps_act=None, eps_model=None, eps_out=None):
+        """CemMpc.generate_action (cem_mpc.py:31-33): state[O] -> (action[A], best_score, iters)."""
+        c = self.cfg
+        st = np.ascontiguousarray(np.asarray(state, np.float32))
+        if st.shape != (c.obs_dim,):
+            raise ValueError('state must have shape [%d]' % c.obs_dim)
+        if call is None:
+            call = self._call
+            self._call += 1
+        ea, em = self._noise_args(eps_act, eps_model)
+        eo = np.ascontiguousarray(np.asarray(eps_out, np.float32)) if eps_out is not None else None
+        action = np.zeros(c.act_dim, np.float32)
+        score = C.c_float()
+        iters = C.c_int32()
+        _capi.check(self.lib.cem_planner_plan(self.h, _np_ptr(st), seed, call, _ptr(ea), _ptr(em), _np_ptr(eo),
+                                              _np_ptr(action), C.byref(score), C.byref(iters)), 'cem_planner_plan')
+        return action, float(score.value), int(iters.value)
+
+    def plan_begin(self, state, seed=0, call=0, eps_act=None, eps_model=None):
+        st = np.ascontiguousarray(np.asarray(state, np.float32))
+        ea, em = self._noise_args(eps_act, eps_model)
+        self._keep = (ea, em)
+        _capi.check(self.lib.cem_plan_begin(self.h, _np_ptr(st), seed, call, _ptr(ea), _ptr(em)), 'cem_plan_begin')
+
+    def plan_rollout(self, it):
+        _capi.check(self.lib.cem_plan_rollout(self.h, it), 'cem_plan_rollout')
+
+    def plan_select(self, it):
+        _capi.check(self.lib.cem_plan_select(self.h, it), 'cem_plan_select')
+
+    def plan_end(self, eps_out=None):
+        c = self.cfg
+        eo = np.ascontiguousarray(np.asarray(eps_out, np.float32)) if eps_out is not None else None
+        action = np.zeros(c.act_dim, np.float32)
+        score = C.c_float()
+        iters = C.c_int32()
+        _capi.check(self.lib.cem_plan_end(self.h, _np_ptr(eo), _np_ptr(action), C.byref(score), C.byref(iters)), 'cem_plan_end')
+        self._keep = None
+        return action, float(score.value), int(iters.value)
+
+    # ------------------------------------------------------------------ model API
+    def unfold_sequences(self, s0, actions, eps_model=None, seed=0, call=0, return_moments=False):
+        """TransitionModel.unfold_sequences (transition_model.py:64-77) on device:
+        s0 [B,O], actions [B,H,A] -> traj [B,H+1,O] (torch tensors on the GPU)."""
+        t = self._torch
+        c = self.cfg
+        s0 = t.as_tensor(s0, dtype=t.float32, device=self.device).contiguous()
+        actions = t.as_tensor(actions, dtype=t.float32, device=self.device).contiguous()
+        B, H = actions.shape[0], actions.shape[1]
+        if tuple(s0.shape) != (B, c.obs_dim) or actions.shape[2] != c.act_dim:
+            raise ValueError('bad shapes for unfold_sequences')
+        em = None
+        if eps_model is not None:
+            em = t.as_tensor(eps_model, dtype=t.float32, device=self.device).contiguous()
+            if tuple(em.shape) != (H, B, c.obs_dim):
+                raise ValueError('eps_model must be [H,B,O]')
+        traj = t.empty((B, H + 1, c.obs_dim), dtype=t.float32, device=self.device)
+        mu = t.empty((B, H, c.obs_dim), dtype=t.float32, device=self.device) if return_moments else None
+        sd = t.empty((B, H, c.obs_dim), dtype=t.float32, device=self.device) if return_moments else None
+        _capi.check(self.lib.cem_unfold_sequences(self.h, _ptr(s0), _ptr(actions), B, H, _ptr(em), seed, call,
+                                                  _ptr(traj), _ptr(mu), _ptr(sd)), 'cem_unfold_sequences')
+        return (traj, mu, sd) if return_moments else traj
+
+    def fill_noise(self, seed=0, call=0):
+        """The Philox streams a (seed, call) plan consumes, as explicit tensors."""
+        t = self._torch
+        c = self.cfg
+        B = c.particles * c.n_samples
+        ea = t.empty((c.iterations, c.n_samples, c.horizon, c.act_dim), dtype=t.float32, device=self.device)
+        em = t.empty((c.iterations, c.horizon, B, c.obs_dim), dtype=t.float32, device=self.device)
+        eo = t.empty((c.act_dim,), dtype=t.float32, device=self.device)
+        _capi.check(self.lib.cem_fill_noise(self.h, seed, call, _ptr(ea), _ptr(em), _ptr(eo)), 'cem_fill_noise')
+        return ea, em, eo
+
+    def set_timing(self, enable=True):
+        _capi.check(self.lib.cem_planner_set_timing(self.h, int(enable)), 'cem_planner_set_timing')
+
+    def last_timing(self):
+        r, n, s = C.c_float(), C.c_int32(), C.c_float()
+        _capi.check(self.lib.cem_planner_last_timing(self.h, C.byref(r), C.byref(n), C.byref(s)), 'cem_planner_last_timing')
+        return dict(rollout_ms=float(r.value), rollout_launches=int(n.value), select_ms=float(s.value))
+
+    def tiles(self):
+        """(chunks_per_tile, tiles[n,6]) of this handle's plan (host-side logic, no GPU call)."""
+        return plan_tiles(self.cfg)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.cem_planner_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def plan_tiles(cfg: PlannerConfig):
+    lib = _capi.load()
+    cc = to_c_config(cfg)
+    rc, nt = C.c_int32(), C.c_int32()
+    _capi.check(lib.cem_plan_tiles_host(C.byref(cc), C.byref(rc), C.byref(nt), None, 0), 'cem_plan_tiles_host')
+    tiles = np.zeros((nt.value, 6), np.int32)
+    _capi.check(lib.cem_plan_tiles_host(C.byref(cc), C.byref(rc), C.byref(nt), _np_ptr(tiles), nt.value), 'cem_plan_tiles_host')
+    return rc.value, tiles
+
+
+def pack_weights_host(cfg: PlannerConfig, weights) -> np.ndarray:
+    lib = _capi.load()
+    cc = to_c_config(cfg)
+    blob = flatten_weights(weights)
+    out = np.zeros(lib.cem_packed_weight_floats(C.byref(cc)), np.float32)
+    _capi.check(lib.cem_pack_weights_host(C.byref(cc), _np_ptr(blob), _np_ptr(out)), 'cem_pack_weights_host')
+    return out

@@ -1,0 +1,172 @@
+/*
+ * cem_mpc.h — C ABI of the MI355X-native CEM-MPC planner (libcem_mpc_gfx950.so).
+ *
+ * Drop-in boundary for ONE path of yardenas/ethz-safe-learning ("simba"):
+ *   CemMpc.generate_action / do_generate_action      simba/policies/cem_mpc.py:31-68
+ *   SafeCemMpc.compute_objective                     simba/policies/safe_cem_mpc.py:76-120
+ *   MpcPolicy.compute_objective / sampling_params    simba/policies/mpc_policy.py:26-57
+ *   TransitionModel.unfold_sequences / scale         simba/models/transition_model.py:64-87
+ *   MlpEnsemble.forward / __call__                   simba/models/mlp_ensemble.py:122-132,189-193
+ *   SafetyGymStateScorer.reward / cost ('goal' task) simba/environment_utils/safety_gym.py:110-192
+ *
+ * The reference is pure Python on TensorFlow; it has no FFI of its own.  These
+ * entry points are what a ctypes binding inside simba/policies/cem_mpc.py would
+ * call (INTEGRATION.md shows that binding).  Plain pointers and sizes only; no
+ * torch types.  Device memory (the workspace, optional noise tensors) is owned
+ * by the caller (torch-ROCm tensors or hipMalloc), the HIP stream is the
+ * caller's.  Every function returns an int status (CEM_OK == 0); nothing
+ * throws across the boundary.  A handle is not thread-safe; one plan in flight
+ * per handle (the reference has one synchronous caller, simba/agents/agent.py:120).
+ * A shape change (scripts/tune_cem_policy.py:109-115) = a new handle.
+ */
+#ifndef CEM_MPC_H
+#define CEM_MPC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CEM_ABI_VERSION 1
+#define CEM_MAX_ACT 32
+#define CEM_MAX_COST_KINDS 4
+
+enum cem_status {
+    CEM_OK = 0,
+    CEM_ERR_INVALID_ARG = 1,     /* NULL pointer / bad dims */
+    CEM_ERR_UNSUPPORTED = 2,     /* e.g. units != 128, task 'push', obs+act > 128 */
+    CEM_ERR_SPLIT = 3,           /* (particles*n_samples) % ensemble_size != 0: tf.split would raise (mlp_ensemble.py:123) */
+    CEM_ERR_WORKSPACE = 4,       /* workspace too small / misaligned */
+    CEM_ERR_HIP = 5,             /* a HIP runtime call failed; cem_last_hip_error() has the code */
+    CEM_ERR_NO_WEIGHTS = 6,      /* plan() before set_weights() */
+    CEM_ERR_STATE = 7            /* stepwise calls out of order */
+};
+
+enum cem_variant { CEM_VARIANT_CEM = 0 /* CemMpc */, CEM_VARIANT_SAFE = 1 /* SafeCemMpc */ };
+
+/* SafetyGymStateScorer fields used by the 'goal' task (safety_gym.py:104-176).
+ * The constants come from safety_gym's Engine config (absent from the
+ * reference tree), hence explicit. */
+typedef struct cem_scorer {
+    int32_t goal_mode;            /* 0: observe_goal_lidar (closest_distance over goal slice); 1: observe_goal_dist (relu of one feature) */
+    int32_t goal_lo, goal_hi;     /* sensor_offset_table['goal_lidar'|'goal_dist'] */
+    float lidar_max_dist;
+    float goal_size;
+    float reward_distance;
+    float reward_goal;
+    float reward_clip;            /* <= 0: no clip (safety_gym.py:141) */
+    int32_t constrain_indicator;
+    int32_t n_cost_kinds;         /* constrained kinds, reference order vases,hazards,pillars,gremlins (safety_gym.py:148-163) */
+    int32_t cost_lo[CEM_MAX_COST_KINDS];
+    int32_t cost_hi[CEM_MAX_COST_KINDS];
+    float cost_size[CEM_MAX_COST_KINDS];
+} cem_scorer_t;
+
+/* Constructor kwargs of CemMpc / SafeCemMpc (cem_mpc.py:7-17, safe_cem_mpc.py:8-19)
+ * + the model dims of TransitionModel/MlpEnsemble (transition_model.py:8-21,
+ * config/models.yaml) + candidate sharding. */
+typedef struct cem_config {
+    int32_t abi_version;          /* CEM_ABI_VERSION */
+    int32_t obs_dim, act_dim;
+    int32_t units, n_layers;      /* mlp_params (units must be 128 in this build) */
+    int32_t ensemble_size;        /* E */
+    int32_t particles;            /* P */
+    int32_t n_samples;            /* N (global, over all ranks) */
+    int32_t horizon;              /* H */
+    int32_t n_elite;              /* k */
+    int32_t iterations;           /* I */
+    float smoothing;
+    float stddev_threshold;
+    float noise_stddev;
+    int32_t variant;              /* enum cem_variant */
+    float posterior_mean_threashold;   /* sic: the YAML key, config/policies.yaml:20 */
+    int32_t sampling_propagation; /* config/agents.yaml:14 */
+    int32_t scale_features;       /* config/agents.yaml:13 */
+    /* MpcPolicy.sampling_params (mpc_policy.py:45-57), resolved by the caller */
+    float act_lb[CEM_MAX_ACT], act_ub[CEM_MAX_ACT], act_mu0[CEM_MAX_ACT], act_sigma0[CEM_MAX_ACT];
+    cem_scorer_t scorer;
+    /* candidate sharding: this rank owns candidates [rank*N/world, (rank+1)*N/world) x all particles */
+    int32_t world_size, rank;
+    int32_t chunks_per_tile;      /* 0 = auto; 1..4 = 16-row chunks per workgroup tile */
+    int32_t use_graph;            /* 1: capture the whole plan in a hipGraph (single-rank, Philox noise only) */
+} cem_config_t;
+
+/* Byte offsets into the caller's workspace of the arrays a host binding needs
+ * (torch views for the collective, debug outputs). */
+typedef struct cem_layout {
+    size_t scores_local;   /* float [N/world]   — this rank's candidate scores (input to the collective) */
+    size_t scores_global;  /* float [N]         — all candidates' scores (output of the collective; == scores_local slot for world 1) */
+    size_t actions;        /* float [N][H][A]   — the current iteration's clipped action sequences */
+    size_t mu_sigma;       /* float [2][H][A]   — sampling mean, stddev */
+    size_t elite_idx;      /* int32 [k]         — elite set of the last select, ascending index */
+    size_t returns;        /* float [P*N/world] — per-row done-masked return of the last rollout */
+    size_t costs;          /* uint8 [H][P*N/world] — per-step masked cost (safe variant) */
+    size_t result;         /* float [A] action, float best_score, int32 iters, int32 done */
+    size_t total;
+} cem_layout_t;
+
+typedef struct cem_planner cem_planner_t;
+
+int cem_abi_version(void);
+const char *cem_status_string(int status);
+int cem_last_hip_error(void);
+
+/* natural (Keras) weight blob: per member m, in order
+ *   W_0[obs+act][U], b_0[U], W_1[U][U], b_1[U], ... W_{L-1}, b_{L-1},
+ *   W_mu[U][obs], b_mu[obs], W_var[U][obs], b_var[obs]        (all row-major [in][out], mlp_ensemble.py:13,28-29) */
+size_t cem_weight_blob_floats(const cem_config_t *cfg);
+size_t cem_packed_weight_floats(const cem_config_t *cfg);
+size_t cem_workspace_bytes(const cem_config_t *cfg);
+
+/* host-only helpers (no GPU needed; exercised by the CPU test-suite) */
+int cem_pack_weights_host(const cem_config_t *cfg, const float *blob, float *packed);
+int cem_plan_tiles_host(const cem_config_t *cfg, int32_t *chunks_per_tile_out, int32_t *n_tiles_out,
+                        int32_t *tiles_out /* [n_tiles][6]: row_base,cnt,member,act_base,noise_row_base,s0_base */, int32_t max_tiles);
+
+/* lifecycle.  `workspace` is device memory of >= cem_workspace_bytes(cfg), 256-B aligned; `hip_stream` a hipStream_t (NULL = default). */
+int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspace_bytes, void *hip_stream, cem_planner_t **out);
+int cem_planner_destroy(cem_planner_t *h);
+int cem_planner_layout(const cem_planner_t *h, cem_layout_t *out);
+
+/* weight / normaliser sync after MlpEnsemble.fit and TransitionModel._fit_statistics
+ * (mlp_ensemble.py:143-144, transition_model.py:42-50).  Host pointers. */
+int cem_planner_set_weights(cem_planner_t *h, const float *blob, size_t n_floats);
+int cem_planner_set_normaliser(cem_planner_t *h, const float *inputs_min, const float *inputs_max /* [obs+act] */);
+
+/* CemMpc.generate_action (cem_mpc.py:31-33): state[obs] (host) -> action[act] (host).
+ * Noise: Philox4x32-10 keyed (seed, call) when the eps pointers are NULL, otherwise explicit
+ * DEVICE tensors eps_act[I][N][H][A], eps_model[I][H][P*N][obs] and HOST eps_out[A]
+ * (parity mode: "identical seeds" == identical noise tensors). */
+int cem_planner_plan(cem_planner_t *h, const float *state, uint64_t seed, uint64_t call,
+                     const float *eps_act_dev, const float *eps_model_dev, const float *eps_out_host,
+                     float *action_out, float *best_score_out, int32_t *iters_out);
+
+/* the same plan split at its one exchange step, for candidate-sharded ranks:
+ *   begin; for it: rollout(it) -> [collective on scores_local -> scores_global] -> select(it); end */
+int cem_plan_begin(cem_planner_t *h, const float *state, uint64_t seed, uint64_t call,
+                   const float *eps_act_dev, const float *eps_model_dev);
+int cem_plan_rollout(cem_planner_t *h, int32_t it);   /* sample actions, roll out + score this rank's candidates -> scores_local */
+int cem_plan_select(cem_planner_t *h, int32_t it);    /* top-k / moments refit / best-so-far / early-stop on scores_global */
+int cem_plan_end(cem_planner_t *h, const float *eps_out_host, float *action_out, float *best_score_out, int32_t *iters_out);
+
+/* TransitionModel.unfold_sequences (transition_model.py:64-77) as an API of its own:
+ * s0[B][obs], actions[B][H][A] (device) -> traj[B][H+1][obs] (device); optional mu/stddev[B][H][obs].
+ * Row r uses member r / (B/E).  Noise: eps_model_dev[H][B][obs] or Philox (seed, call). */
+int cem_unfold_sequences(cem_planner_t *h, const float *s0_dev, const float *actions_dev, int32_t n_rows, int32_t horizon,
+                         const float *eps_model_dev, uint64_t seed, uint64_t call,
+                         float *traj_out_dev, float *mu_out_dev, float *sd_out_dev);
+
+/* dump the Philox streams a (seed, call) plan consumes, in the explicit-tensor layouts above (device pointers; any may be NULL) */
+int cem_fill_noise(cem_planner_t *h, uint64_t seed, uint64_t call, float *eps_act_dev, float *eps_model_dev, float *eps_out_dev);
+
+/* device time (ms) of the rollout kernels of the last plan, measured with HIP events on the handle's stream
+ * (enabled by cem_planner_set_timing(h, 1); costs one event pair per launch). */
+int cem_planner_set_timing(cem_planner_t *h, int32_t enable);
+int cem_planner_last_timing(cem_planner_t *h, float *rollout_ms_total, int32_t *rollout_launches, float *select_ms_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CEM_MPC_H */
