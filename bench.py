@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py — planning steps/sec of the MI355X CEM-MPC planner (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+(one rank per GPU, RCCL).  A "step" is one complete plan = CemMpc.generate_action: I=5 CEM iterations of
+sample -> rollout+score -> select/refit, early stop disabled so exactly I iterations run.
+
+Workload: BASELINE config B2 (obs=60, act=2, K=P=E=5, N=2000, H=30, I=5, k=N/10) at N=1.  At G>1 the candidate
+count is weak-scaled (N = 2000*G, every rank rolls out 2000 candidates x 5 particles) and `value` is in
+B2-equivalent plans/s = candidate-trajectory-steps/s / 300000, so it equals plain plans/s at G=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
+
+
+def cpu_baseline(pb, obs, act, K, N, H, I, k, budget_s=25.0):
+    """The oracle (a port: numpy restatement of the reference's path) timed on this box's host cores on a bounded
+    sample of the same workload: whole B2 plans until ~budget_s of CPU time is spent (at least one)."""
+    from oracle import cem_oracle as o      # cpu_baseline leg only
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    sp = pb['scorer']
+    osp = o.ScorerParams(goal_slice=sp.goal_slice, observe_goal_lidar=sp.observe_goal_lidar, lidar_max_dist=sp.lidar_max_dist,
+                         goal_size=sp.goal_size, reward_distance=sp.reward_distance, reward_goal=sp.reward_goal,
+                         reward_clip=sp.reward_clip, constrain_indicator=sp.constrain_indicator, cost_kinds=list(sp.cost_kinds))
+    cfg = o.PlanConfig(horizon=H, iterations=I, n_samples=N, n_elite=k, particles=K, ensemble_size=K, stddev_threshold=-1.0,
+                       noise_stddev=1e-3)
+    rng = np.random.default_rng(2026)
+    plans, t_total = 0, 0.0
+    while plans == 0 or (t_total < budget_s and plans < 8):
+        ea = rng.standard_normal((I, N, H, act)).astype(np.float32)
+        em = rng.standard_normal((I, H, K * N, obs)).astype(np.float32)
+        eo = rng.standard_normal((act,)).astype(np.float32)
+        t0 = time.perf_counter()
+        o.do_generate_action(pb['state'], pb['weights'], pb['inputs_min'], pb['inputs_max'], pb['low'], pb['high'],
+                             ea, em, eo, cfg, osp)
+        t_total += time.perf_counter() - t0
+        plans += 1
+    return dict(value=plans / t_total, unit='plans/s', cores=int(cores), kind='port',
+                sample='%d full B2 plan(s) (N=%d,H=%d,K=%d,I=%d) through oracle/cem_oracle.py (numpy fp32, BLAS threads=%d), '
+                       'noise generation excluded' % (plans, N, H, K, I, cores))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--chunks', type=int, default=0)
+    ap.add_argument('--n-per-gpu', type=int, default=2000)
+    args = ap.parse_args()
+
+    import torch
+    from ethz_safe_learning_amd import CemPlanner, PlannerConfig, synthetic
+    from ethz_safe_learning_amd.sharded import ShardedCemDriver
+
+    G = args.gpus
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if G > 1:
+        assert world == G, 'launch with torch.distributed.run --nproc-per-node %d' % G
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = 'cuda:%d' % (local_rank if G > 1 else 0)
+
+    obs, act, K, H, I = 60, 2, 5, 30, 5
+    N = args.n_per_gpu * G
+    k = N // 10                                       # the reference's elite ratio for cem_mpc (policies.yaml:6-7)
+    pb = synthetic.problem(obs, act, K)
+    cfg = PlannerConfig(obs_dim=obs, act_dim=act, ensemble_size=K, particles=K, n_samples=N, horizon=H, n_elite=k,
+                        iterations=I, scorer=pb['scorer'], act_low=pb['low'], act_high=pb['high'], stddev_threshold=-1.0,
+                        noise_stddev=1e-3, variant='cem', world_size=G, rank=rank, chunks_per_tile=args.chunks,
+                        use_graph=(G == 1 and not args.no_graph))
+    pl = CemPlanner(cfg, device=dev)
+    pl.set_weights(pb['weights'])
+    pl.set_normaliser(pb['inputs_min'], pb['inputs_max'])
+    drv = ShardedCemDriver(pl, I, world_size=G)
+
+    def one_plan(i):
+        if G == 1:
+            return pl.plan(pb['state'], seed=2026, call=i)
+        return drv.plan(pb['state'], seed=2026, call=i)
+
+    for i in range(args.warmup):
+        one_plan(i)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        a, s, it = one_plan(args.warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert it == I and np.all(np.isfinite(a))
+
+    # roofline of the dominant kernel: HIP events on the handle's stream around every rollout launch (eager launches)
+    pl.set_timing(True)
+    roll_ms, roll_n = 0.0, 0
+    for i in range(5):
+        if G == 1:
+            pl.plan(pb['state'], seed=2027, call=i)
+        else:
+            drv.plan(pb['state'], seed=2027, call=i)
+        tm = pl.last_timing()
+        roll_ms += tm['rollout_ms']; roll_n += tm['rollout_launches']
+    pl.set_timing(False)
+    flops_launch = synthetic.flops_per_row_step(obs, act) * K * (N // G) * H
+    avg_ms = roll_ms / max(roll_n, 1)
+    achieved = flops_launch / (avg_ms * 1e-3) / 1e12
+
+    plans_per_s = args.steps / dt
+    b2_equiv = plans_per_s * (N / 2000.0)
+    out = {
+        'metric': 'planning steps/sec (CEM-MPC, N=2000 K=5 H=30)', 'value': b2_equiv, 'unit': 'plans/s',
+        'n_gpus': G, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'B2: obs=60 act=2 K=P=E=5 N=%d H=30 I=5 k=N/10 units=128 layers=4, CemMpc objective, early stop off%s'
+                               % (N, '' if G == 1 else ' (weak-scaled: 2000 candidates per GPU, value in B2-equivalent plans/s)'),
+                   'candidates_per_gpu': N // G, 'chunks_per_tile': pl.tiles()[0], 'workgroups': int(len(pl.tiles()[1])),
+                   'hip_graph': bool(cfg.use_graph), 'parallelism': 'candidates sharded x%d, 1 all-gather of scores/iter' % G},
+        'candidate_trajectory_steps_per_s': plans_per_s * I * N * H,
+        'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                     'kernel': 'cem_rollout_kernel', 'avg_launch_ms': avg_ms, 'launches_timed': roll_n,
+                     'algorithmic_flops_per_launch': flops_launch},
+    }
+    if rank == 0 and G == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(pb, obs, act, K, args.n_per_gpu, H, I, args.n_per_gpu // 10)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -209,6 +209,7 @@ struct cem_planner {
     Layout lay;
     char *ws;
     hipStream_t stream;
+    bool own_stream;
     int rc;
     int n_tiles;
     bool have_weights;
@@ -300,7 +301,11 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
     h->cfg = *cfg; h->d = make_dims(cfg);
     h->lay = make_layout(cfg, h->d, max_tiles_of(h->d));
     if (workspace_bytes < h->lay.total || ((uintptr_t)workspace & 255)) { delete h; return CEM_ERR_WORKSPACE; }
-    h->ws = (char *)workspace; h->stream = (hipStream_t)hip_stream;
+    h->ws = (char *)workspace; h->stream = (hipStream_t)hip_stream; h->own_stream = false;
+    if (!h->stream) {      // the legacy default stream cannot be captured into a hipGraph: use a stream of our own
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { g_last_hip = (int)hipGetLastError(); delete h; return CEM_ERR_HIP; }
+        h->own_stream = true;
+    }
     h->rc = cfg->chunks_per_tile ? cfg->chunks_per_tile : auto_chunks(h->d);
     h->have_weights = false; h->in_plan = false; h->eps_act = h->eps_model = nullptr;
     h->timing = false; h->roll_ms = h->sel_ms = 0.f; h->roll_n = 0;
@@ -346,6 +351,7 @@ int cem_planner_destroy(cem_planner_t *h)
     for (auto e : h->ev) hipEventDestroy(e);
     if (h->h_ctrl) hipHostFree(h->h_ctrl);
     if (h->h_result) hipHostFree(h->h_result);
+    if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
     return CEM_OK;
 }

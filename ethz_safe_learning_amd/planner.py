@@ -148,7 +148,9 @@ class CemPlanner:
             self.workspace = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.device)
             off = (-self.workspace.data_ptr()) % 256
             self._ws_view = self.workspace[off:off + nbytes]
-            self.stream = torch.cuda.current_stream(self.device)
+            # a stream of the planner's own: the legacy default stream cannot be captured into a hipGraph
+            self.stream = torch.cuda.Stream(device=self.device)
+            torch.cuda.synchronize(self.device)         # workspace zero-fill (default stream) before the library uses it
             h = C.c_void_p()
             _capi.check(self.lib.cem_planner_create(C.byref(self.ccfg), _ptr(self._ws_view), nbytes,
                                                     C.c_void_p(self.stream.cuda_stream), C.byref(h)), 'cem_planner_create')
@@ -157,6 +159,18 @@ class CemPlanner:
         _capi.check(self.lib.cem_planner_layout(self.h, C.byref(lay)), 'cem_planner_layout')
         self.layout = lay
         self._call = 0
+
+    # ------------------------------------------------------------------ stream plumbing
+    def _wait_inputs(self):
+        """Order the planner's stream after whatever torch's current stream has queued (input tensors)."""
+        self.stream.wait_stream(self._torch.cuda.current_stream(self.device))
+
+    def stream_context(self):
+        """Context in which torch ops (the RCCL collective on the score buffers) run on the planner's stream."""
+        return self._torch.cuda.stream(self.stream)
+
+    def synchronize(self):
+        self.stream.synchronize()
 
     # ------------------------------------------------------------------ views
     def _view(self, off, count, dtype):
@@ -241,6 +255,8 @@ class CemPlanner:
         action = np.zeros(c.act_dim, np.float32)
         score = C.c_float()
         iters = C.c_int32()
+        if ea is not None:
+            self._wait_inputs()
         _capi.check(self.lib.cem_planner_plan(self.h, _np_ptr(st), seed, call, _ptr(ea), _ptr(em), _np_ptr(eo),
                                               _np_ptr(action), C.byref(score), C.byref(iters)), 'cem_planner_plan')
         return action, float(score.value), int(iters.value)
@@ -249,6 +265,7 @@ class CemPlanner:
         st = np.ascontiguousarray(np.asarray(state, np.float32))
         ea, em = self._noise_args(eps_act, eps_model)
         self._keep = (ea, em)
+        self._wait_inputs()
         _capi.check(self.lib.cem_plan_begin(self.h, _np_ptr(st), seed, call, _ptr(ea), _ptr(em)), 'cem_plan_begin')
 
     def plan_rollout(self, it):
@@ -286,6 +303,7 @@ class CemPlanner:
         traj = t.empty((B, H + 1, c.obs_dim), dtype=t.float32, device=self.device)
         mu = t.empty((B, H, c.obs_dim), dtype=t.float32, device=self.device) if return_moments else None
         sd = t.empty((B, H, c.obs_dim), dtype=t.float32, device=self.device) if return_moments else None
+        self._wait_inputs()
         _capi.check(self.lib.cem_unfold_sequences(self.h, _ptr(s0), _ptr(actions), B, H, _ptr(em), seed, call,
                                                   _ptr(traj), _ptr(mu), _ptr(sd)), 'cem_unfold_sequences')
         return (traj, mu, sd) if return_moments else traj
@@ -298,6 +316,7 @@ class CemPlanner:
         ea = t.empty((c.iterations, c.n_samples, c.horizon, c.act_dim), dtype=t.float32, device=self.device)
         em = t.empty((c.iterations, c.horizon, B, c.obs_dim), dtype=t.float32, device=self.device)
         eo = t.empty((c.act_dim,), dtype=t.float32, device=self.device)
+        self._wait_inputs()
         _capi.check(self.lib.cem_fill_noise(self.h, seed, call, _ptr(ea), _ptr(em), _ptr(eo)), 'cem_fill_noise')
         return ea, em, eo
 

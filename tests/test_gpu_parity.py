@@ -1,0 +1,324 @@
+"""Parity of the HIP path (through the C ABI) against the oracle on shared noise tensors.
+
+Tolerances (fp32 path, north-star: elite actions within 1e-5 rel):
+  * trajectories / head moments / per-row returns: |gpu - oracle64| <= 5e-5 absolute on O(1) quantities.  Both fp32
+    implementations (numpy's BLAS order and the MFMA's k-ordered fma chain) sit ~1e-6 from the fp64 shadow after H
+    recurrent steps; the bound leaves room for the amplification SURVEY section 7 warns about.
+  * `<=` thresholds (goal reached, hazard hit) and top-k membership are discontinuous: rows/candidates whose fp64
+    margin to a threshold is below 1e-4 are excluded from exact comparisons (and must be few).
+  * sampled actions: bit-exact.  Selection given identical scores: bit-exact elite set, mu/sigma within 1e-6.
+"""
+import numpy as np
+import pytest
+
+from oracle import cem_oracle as o
+from tests import helpers as hp
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 5e-5
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), 'gpu tests need an MI355X'
+    return torch
+
+
+# ------------------------------------------------------------------------------------------------- unfold
+@pytest.mark.parametrize('O,A,E,L,B,H,sampling,scale', [
+    (60, 2, 5, 4, 400, 6, True, True),          # PointGoal1 dims, tiles of 16 rows
+    (60, 2, 5, 4, 35, 3, True, True),           # ragged: 7 rows per member
+    (6, 2, 2, 2, 64, 4, True, True),            # one input block (KB_in = 1): waves 1-3 own no features
+    (100, 12, 8, 4, 128, 5, True, True),        # Doggo-scale: two owned blocks per wave (NFW = 2)
+    (64, 2, 2, 2, 32, 3, True, True),           # an input block made of action features only
+    (60, 2, 5, 4, 80, 4, False, True),          # sampling_propagation: False (experiment_no_sample.yaml:14-16)
+    (60, 2, 5, 4, 80, 4, True, False),          # scale_features False
+    (60, 2, 5, 1, 80, 3, True, True),           # a single hidden layer
+])
+def test_unfold_sequences_matches_oracle(O, A, E, L, B, H, sampling, scale):
+    torch = _torch()
+    pb = hp.make_problem(O, A, E, L, seed=21)
+    ocfg, pcfg = hp.configs(pb, N=16 * E, H=H, P=E, E=E, k=4, sampling=sampling, scale=scale)
+    pl = hp.make_planner(pb, pcfg)
+    rng = np.random.default_rng(5)
+    s0 = (pb['state'][None, :] + 0.05 * rng.standard_normal((B, O))).astype(np.float32)
+    acts = rng.uniform(-1, 1, (B, H, A)).astype(np.float32)
+    eps = rng.standard_normal((H, B, O)).astype(np.float32)
+    traj, mu, sd = pl.unfold_sequences(s0, acts, eps_model=eps, return_moments=True)
+    traj, mu, sd = traj.cpu().numpy(), mu.cpu().numpy(), sd.cpu().numpy()
+    members = o.member_of_rows(B, E)
+    w64 = o.cast_weights(pb['weights'], np.float64)
+    ref64 = o.unfold_sequences(s0.astype(np.float64), acts.astype(np.float64), w64, members, pb['inputs_min'], pb['inputs_max'],
+                               eps.astype(np.float64), scale, sampling)
+    ref32 = o.unfold_sequences(s0, acts, pb['weights'], members, pb['inputs_min'], pb['inputs_max'], eps, scale, sampling)
+    np.testing.assert_array_equal(traj[:, 0], s0)
+    err_gpu = np.abs(traj - ref64).max()
+    err_np = np.abs(ref32 - ref64).max()
+    print('unfold max|gpu-f64| = %.3g, max|numpy32-f64| = %.3g' % (err_gpu, err_np))
+    assert err_gpu <= ATOL
+    # head moments of the first step (same inputs on both sides)
+    x0 = o.scale(np.concatenate([s0, acts[:, 0]], 1).astype(np.float64), pb['inputs_min'], pb['inputs_max'], scale)
+    m64, v64 = o.ensemble_forward(x0, w64, members)
+    np.testing.assert_allclose(mu[:, 0], m64, atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(sd[:, 0], np.sqrt(v64), atol=2e-6, rtol=1e-5)
+
+
+def test_unfold_philox_equals_dumped_noise():
+    torch = _torch()
+    pb = hp.make_problem(seed=4)
+    ocfg, pcfg = hp.configs(pb, N=32, H=5, P=5, E=5, k=4, I=2)
+    pl = hp.make_planner(pb, pcfg)
+    ea, em, eo = pl.fill_noise(seed=77, call=3)
+    B = 5 * 32
+    rng = np.random.default_rng(0)
+    s0 = np.broadcast_to(pb['state'], (B, 60)).copy()
+    acts = rng.uniform(-1, 1, (B, 5, 2)).astype(np.float32)
+    t_philox = pl.unfold_sequences(s0, acts, seed=77, call=3)
+    t_tensor = pl.unfold_sequences(s0, acts, eps_model=em[0])
+    assert torch.equal(t_philox, t_tensor)
+    # the stream is standard normal
+    z = em.cpu().numpy().ravel()
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02 and np.abs(z).max() < 6.5
+
+
+# ------------------------------------------------------------------------------------------------- one iteration
+def _run_iteration(pl, pb, ocfg, ea, em, it=0):
+    pl.plan_begin(pb['state'], eps_act=ea, eps_model=em)
+    for i in range(it + 1):
+        pl.plan_rollout(i)
+        if i < it:
+            pl.plan_select(i)
+    torch = _torch()
+    torch.cuda.synchronize()
+    return (pl.actions().cpu().numpy().copy(), pl.returns().cpu().numpy().copy(), pl.scores_local().cpu().numpy().copy())
+
+
+@pytest.mark.parametrize('variant,P,E,N,H,post', [
+    ('cem', 5, 5, 96, 12, 0.15),
+    ('safe', 5, 5, 96, 12, 0.3),
+    ('safe', 6, 3, 40, 8, 0.3),        # two particles per member; ragged tiles
+    ('cem', 5, 15, 150, 8, 0.15),      # shipped cem_mpc shape: candidates of one particle hit 3 members
+])
+def test_rollout_scores_match_oracle(variant, P, E, N, H, post):
+    torch = _torch()
+    pb = hp.make_problem(E=E, seed=31)
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=max(2, N // 10), I=1, variant=variant, post=post)
+    pl = hp.make_planner(pb, pcfg)
+    ea, em, eo = hp.noise(1, N, H, 2, P, 60, seed=8)
+    actions, returns, scores = _run_iteration(pl, pb, ocfg, ea, em)
+    lb, ub, mu0, sg0 = o.sampling_params(pb['low'], pb['high'])
+    ref_actions = o.sample_actions(np.broadcast_to(mu0, (H, 2)), np.broadcast_to(sg0, (H, 2)), lb, ub, ea[0])
+    np.testing.assert_array_equal(actions, ref_actions)                       # bit-exact sampling + clip
+    w64 = o.cast_weights(pb['weights'], np.float64)
+    ref64, traj64 = o.candidate_scores(pb['state'].astype(np.float64), ref_actions.astype(np.float64), w64, pb['inputs_min'],
+                                       pb['inputs_max'], em[0], ocfg, pb['scorer'], return_traj=True)
+    margins = o.threshold_margins(traj64, pb['scorer']).reshape(P, N).min(axis=0)
+    ok = margins > 1e-4
+    assert ok.mean() > 0.9, 'too many candidates on a threshold for a meaningful test'
+    err = np.abs(scores - ref64)[ok].max()
+    print('%s scores: max|gpu-f64| = %.3g over %d/%d candidates' % (variant, err, ok.sum(), N))
+    assert err <= ATOL
+    if variant == 'safe':
+        assert (ref64 < -50).any() and (ref64 > -50).any(), 'test should see both safe and unsafe candidates'
+
+
+def test_select_is_exact_on_given_scores():
+    """top_k / best-so-far / moments on the scores the GPU itself produced: elite set bit-exact vs the oracle."""
+    torch = _torch()
+    pb = hp.make_problem(seed=41)
+    N, H, P, E, k = 200, 6, 5, 5, 20
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=2, smoothing=0.25)
+    pl = hp.make_planner(pb, pcfg)
+    ea, em, eo = hp.noise(2, N, H, 2, P, 60, seed=9)
+    actions, returns, scores = _run_iteration(pl, pb, ocfg, ea, em)
+    ms0 = pl.mu_sigma().cpu().numpy().copy()
+    pl.plan_select(0)
+    torch.cuda.synchronize()
+    elite = np.sort(pl.elite_idx().cpu().numpy())
+    ms1 = pl.mu_sigma().cpu().numpy()
+    mu, sigma, best, best_score, ref_elite, stop = o.select_and_refit(scores, actions, ms0[0], ms0[1], np.zeros(2, np.float32),
+                                                                      np.float32(-np.inf), ocfg)
+    np.testing.assert_array_equal(elite, ref_elite)
+    np.testing.assert_allclose(ms1[0], mu, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(ms1[1], sigma, rtol=1e-5, atol=1e-7)
+    a, s, it = pl.plan_end(eps_out=np.zeros(2, np.float32))
+    np.testing.assert_array_equal(a, best)
+    assert s == best_score and it == 1
+
+
+@pytest.mark.parametrize('case', ['ties', 'all_equal', 'k_equals_n', 'negatives_and_inf', 'large'])
+def test_select_edge_cases(case):
+    """tf.nn.top_k semantics on hand-made score vectors written straight into the score buffer."""
+    torch = _torch()
+    pb = hp.make_problem(seed=42)
+    N = 4096 if case == 'large' else 64
+    k = {'ties': 5, 'all_equal': 7, 'k_equals_n': 64, 'negatives_and_inf': 6, 'large': 409}[case]
+    H = 3
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=5, E=5, k=k, I=1)
+    pl = hp.make_planner(pb, pcfg)
+    ea, em, eo = hp.noise(1, N, H, 2, 5, 60, seed=1)
+    actions, _, _ = _run_iteration(pl, pb, ocfg, ea, em)
+    rng = np.random.default_rng(2)
+    if case == 'ties':
+        sc = np.array([1, 3, 3, 2, 3, 3, 0] + [-1] * (N - 7), np.float32)       # k=5 of six >= 2: 3,3,3,3 then 2
+    elif case == 'all_equal':
+        sc = np.full(N, 0.5, np.float32)                                        # lowest indices win
+    elif case == 'k_equals_n':
+        sc = rng.standard_normal(N).astype(np.float32)
+    elif case == 'negatives_and_inf':
+        sc = rng.standard_normal(N).astype(np.float32) - 100.0
+        sc[10] = np.inf; sc[20] = -np.inf; sc[30] = -0.0; sc[31] = 0.0
+    else:
+        sc = np.round(rng.standard_normal(N), 1).astype(np.float32)             # many exact ties
+    pl.scores_global().copy_(torch.from_numpy(sc))
+    torch.cuda.synchronize()
+    pl.plan_select(0)
+    torch.cuda.synchronize()
+    elite = np.sort(pl.elite_idx().cpu().numpy())
+    np.testing.assert_array_equal(elite, o.top_k(sc, k))
+    a, s, it = pl.plan_end(eps_out=np.zeros(2, np.float32))
+    j = o.best_of_elite(sc, o.top_k(sc, k))
+    assert s == sc[j]
+    np.testing.assert_array_equal(a, actions[j, 0])
+    mean, var = o.moments(actions[o.top_k(sc, k)])
+    ms = pl.mu_sigma().cpu().numpy()
+    np.testing.assert_allclose(ms[0], mean, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ms[1], np.sqrt(var), rtol=1e-4, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------- whole plan
+@pytest.mark.parametrize('variant', ['cem', 'safe'])
+def test_full_plan_matches_oracle(variant):
+    """generate_action end to end on identical noise tensors: per iteration scores, elite set (modulo near ties),
+    mu/sigma and the returned action (elite actions within 1e-5 rel, the north-star tolerance)."""
+    torch = _torch()
+    pb = hp.make_problem(seed=51)
+    N, H, P, E, k, I = 160, 10, 5, 5, 16, 4
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, variant=variant, noise=0.01, post=0.3)
+    pl = hp.make_planner(pb, pcfg)
+    ea, em, eo = hp.noise(I, N, H, 2, P, 60, seed=12)
+    trace = []
+    ra, rs, rit = o.do_generate_action(pb['state'], pb['weights'], pb['inputs_min'], pb['inputs_max'], pb['low'], pb['high'],
+                                       ea, em, eo, ocfg, pb['scorer'], trace=trace)
+    pl.plan_begin(pb['state'], eps_act=ea, eps_model=em)
+    elites_match = True
+    for it in range(I):
+        pl.plan_rollout(it)
+        torch.cuda.synchronize()
+        scores = pl.scores_local().cpu().numpy().copy()
+        if elites_match:
+            np.testing.assert_allclose(pl.actions().cpu().numpy(), trace[it]['actions'], rtol=1e-5, atol=1e-6)
+            bad = np.abs(scores - trace[it]['scores']) > 1e-4
+            assert bad.mean() < 0.05, 'iteration %d: %d/%d scores differ' % (it, bad.sum(), N)
+        pl.plan_select(it)
+        torch.cuda.synchronize()
+        elite = pl.elite_idx().cpu().numpy()
+        if elites_match and set(elite.tolist()) != set(trace[it]['elite'].tolist()):
+            assert hp.elite_sets_equal_modulo_ties(trace[it]['scores'], elite, trace[it]['elite'], 1e-4)
+            elites_match = False          # a near-tie flipped: later iterations legitimately diverge
+        if elites_match:
+            ms = pl.mu_sigma().cpu().numpy()
+            np.testing.assert_allclose(ms[0], trace[it]['mu'], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(ms[1], trace[it]['sigma'], rtol=1e-5, atol=1e-6)
+    a, s, it = pl.plan_end(eps_out=eo)
+    assert it == rit == I
+    if elites_match:
+        np.testing.assert_allclose(a, ra, rtol=1e-5, atol=1e-7)
+        assert abs(s - rs) <= 1e-4
+    print('%s plan: elite sets matched in every iteration: %s' % (variant, elites_match))
+
+
+def test_plan_philox_equals_plan_on_dumped_noise_and_graph():
+    torch = _torch()
+    pb = hp.make_problem(seed=61)
+    N, H, P, E, k, I = 256, 8, 5, 5, 25, 3
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, noise=0.05)
+    pl = hp.make_planner(pb, pcfg)
+    ea, em, eo = pl.fill_noise(seed=5, call=9)
+    a1, s1, i1 = pl.plan(pb['state'], seed=5, call=9)
+    a2, s2, i2 = pl.plan(pb['state'], eps_act=ea, eps_model=em, eps_out=eo.cpu().numpy())
+    np.testing.assert_array_equal(a1, a2)
+    assert s1 == s2 and i1 == i2 == I
+    # and the oracle agrees on that dumped noise
+    ra, rs, rit = o.do_generate_action(pb['state'], pb['weights'], pb['inputs_min'], pb['inputs_max'], pb['low'], pb['high'],
+                                       ea.cpu().numpy(), em.cpu().numpy(), eo.cpu().numpy(), ocfg, pb['scorer'])
+    assert abs(s1 - rs) <= 1e-4
+    # the hipGraph-captured plan is the same computation
+    _, gcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, noise=0.05, use_graph=True)
+    pg = hp.make_planner(pb, gcfg)
+    for _ in range(2):                      # capture, then replay
+        a3, s3, i3 = pg.plan(pb['state'], seed=5, call=9)
+        np.testing.assert_array_equal(a1, a3)
+        assert s1 == s3 and i3 == I
+    a4, _, _ = pg.plan(pb['state'], seed=6, call=9)       # a different seed goes through the replayed graph too
+    assert not np.array_equal(a4, a3)
+
+
+def test_early_stop_and_call_counter():
+    torch = _torch()
+    pb = hp.make_problem(seed=71)
+    ocfg, pcfg = hp.configs(pb, N=128, H=5, P=5, E=5, k=12, I=6, thr=10.0)
+    pl = hp.make_planner(pb, pcfg)
+    a, s, it = pl.plan(pb['state'], seed=1)
+    assert it == 1                               # checked after the first refit (cem_mpc.py:66-67)
+    b, _, _ = pl.plan(pb['state'], seed=1)       # the per-handle call counter gives fresh noise
+    assert not np.array_equal(a, b)
+    c, _, _ = pl.plan(pb['state'], seed=1, call=0)
+    np.testing.assert_array_equal(a, c)          # and (seed, call) reproduces
+
+
+def test_errors_are_loud():
+    from ethz_safe_learning_amd import CemPlanner
+    from ethz_safe_learning_amd._capi import CemError
+    pb = hp.make_problem(seed=1)
+    _, pcfg = hp.configs(pb, N=64, H=3, P=5, E=5, k=4)
+    pl = CemPlanner(pcfg)
+    with pytest.raises(CemError):
+        pl.plan(pb['state'])                     # no weights yet
+    with pytest.raises(ValueError):
+        hp.make_planner(pb, pcfg).plan(np.zeros(3))
+    _, bad = hp.configs(pb, N=7, H=3, P=3, E=5, k=2)
+    with pytest.raises(CemError):
+        CemPlanner(bad)                          # tf.split would raise
+
+
+# ------------------------------------------------------------------------------------------------- full size
+def test_b2_full_size_properties():
+    """BASELINE config B2 (O=60,A=2,K=5,N=2000,H=30): determinism, shard invariance (two half-shards reproduce the
+    single-rank scores bit for bit), chunk-size invariance, and sanity of the scores."""
+    torch = _torch()
+    pb = hp.make_problem(seed=1234, bias_noise=0.0)
+    N, H, P, E, k, I = 2000, 30, 5, 5, 200, 2
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I)
+    pl = hp.make_planner(pb, pcfg)
+
+    def scores_of(planner):
+        planner.plan_begin(pb['state'], seed=3, call=1)
+        planner.plan_rollout(0)
+        torch.cuda.synchronize()
+        return planner.scores_local().cpu().numpy().copy()
+    s_a = scores_of(pl)
+    s_b = scores_of(pl)
+    np.testing.assert_array_equal(s_a, s_b)
+    assert np.isfinite(s_a).all() and s_a.std() > 1e-3
+    halves = []
+    for r in range(2):
+        _, c2 = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, world_size=2, rank=r)
+        halves.append(scores_of(hp.make_planner(pb, c2)))
+    np.testing.assert_array_equal(np.concatenate(halves), s_a)
+    for rc in (1, 2, 4):
+        _, c3 = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, chunks_per_tile=rc)
+        np.testing.assert_array_equal(scores_of(hp.make_planner(pb, c3)), s_a)
+    # a bounded oracle check at full width: the first 64 candidates of iteration 0 on the dumped noise
+    ea, em, eo = pl.fill_noise(seed=3, call=1)
+    sub = 64
+    rows = np.concatenate([p * N + np.arange(sub) for p in range(P)])
+    lb, ub, mu0, sg0 = o.sampling_params(pb['low'], pb['high'])
+    acts = o.sample_actions(np.broadcast_to(mu0, (H, 2)), np.broadcast_to(sg0, (H, 2)), lb, ub, ea[0, :sub].cpu().numpy())
+    ref, traj = o.candidate_scores(pb['state'].astype(np.float64), acts.astype(np.float64), o.cast_weights(pb['weights'], np.float64),
+                                   pb['inputs_min'], pb['inputs_max'], em[0][:, rows].cpu().numpy(), ocfg, pb['scorer'],
+                                   members=o.member_of_rows(P * N, E, rows), return_traj=True)
+    ok = o.threshold_margins(traj, pb['scorer']).reshape(P, sub).min(axis=0) > 1e-4
+    assert ok.sum() > sub // 2
+    assert np.abs(s_a[:sub] - ref)[ok].max() <= 2e-4
