@@ -20,7 +20,7 @@ namespace {
 struct Dims {
     int O, A, Din, U, L, E, P, N, H, k, I, W, R;
     int Nloc, n_off, Bloc, Btot;
-    int KB_in, KB_obs, NFW;
+    int KB_in, KB_obs, NFW, KF0;     // KF0 = 4*NFW: layer-0 groups per wave, zero padded so every stage is a multiple of 4
     int wave_groups[4]; uint32_t wave_off_f4[4]; uint32_t member_stride_f4;
     size_t nat_member_floats;
 };
@@ -52,10 +52,10 @@ Dims make_dims(const cem_config_t *c)
     d.P = c->particles; d.N = c->n_samples; d.H = c->horizon; d.k = c->n_elite; d.I = c->iterations;
     d.W = c->world_size; d.R = c->rank;
     d.Nloc = d.N / d.W; d.n_off = d.R * d.Nloc; d.Bloc = d.P * d.Nloc; d.Btot = d.P * d.N;
-    d.KB_in = (d.Din + 15) / 16; d.KB_obs = (d.O + 15) / 16; d.NFW = (d.KB_in + 3) / 4;
+    d.KB_in = (d.Din + 15) / 16; d.KB_obs = (d.O + 15) / 16; d.NFW = (d.KB_in + 3) / 4; d.KF0 = 4 * d.NFW;
     uint32_t off = 0;
     for (int w = 0; w < 4; ++w) {
-        int g = d.KB_in + CEM_NG * (d.L - 1);
+        int g = d.KF0 + CEM_NG * (d.L - 1);
         for (int i = 0; i < d.NFW; ++i) if (w + 4 * i < d.KB_obs) g += CEM_NG;
         d.wave_groups[w] = g; d.wave_off_f4[w] = off; off += (uint32_t)g * 128u;
     }
@@ -93,7 +93,7 @@ void pack_member(const Dims &d, const float *nat, float *out)
                 }
             }
         };
-        for (int F = 0; F < d.KB_in; ++F) {                       // layer 0
+        for (int F = 0; F < d.KF0; ++F) {                         // layer 0 (groups F >= KB_in are all zero)
             emit(nat + no.W[0], d.Din, d.U, d.U, F, 0, 2 * w); emit(nat + no.W[0], d.Din, d.U, d.U, F, 1, 2 * w + 1);
             dst += 512;
         }
@@ -398,7 +398,7 @@ int cem_planner_set_normaliser(cem_planner_t *h, const float *imin, const float 
         for (int f = 0; f < d.Din; ++f) {
             float delta = imax[f] - imin[f];
             if (delta < 1e-5f) delta = 1.01f;
-            mn[f] = imin[f]; dl[f] = delta;
+            mn[f] = imin[f]; dl[f] = 1.0f / delta;      // the kernel multiplies by 1/delta (<= 1.5 ulp from the reference's division)
         }
     }
     HIPCHK(hipMemcpyAsync(h->ws + h->lay.nmin, mn.data(), CEM_U * 4, hipMemcpyHostToDevice, h->stream));
@@ -414,18 +414,18 @@ int cem_planner_set_normaliser(cem_planner_t *h, const float *imin, const float 
 // ---------------------------------------------------------------------------------------------------------
 namespace {
 
-template <int RC, int NFW, bool DBG>
+template <int RC, int NFW, int MODE>
 hipError_t launch_rollout_t(const RolloutParams &p, int n_tiles, hipStream_t st)
 {
     const size_t lds = (size_t)2 * RC * CEM_NG * 1024 + CEM_PART_FLOATS * 4;
-    hipLaunchKernelGGL((cem_rollout_kernel<RC, NFW, DBG>), dim3(n_tiles), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((cem_rollout_kernel<RC, NFW, MODE>), dim3(n_tiles), dim3(256), lds, st, p);
     return hipGetLastError();
 }
 
-template <bool DBG>
+template <int MODE>
 hipError_t launch_rollout(int rc, int nfw, const RolloutParams &p, int n_tiles, hipStream_t st)
 {
-#define CEM_CASE(R, F) if (rc == R && nfw == F) return launch_rollout_t<R, F, DBG>(p, n_tiles, st);
+#define CEM_CASE(R, F) if (rc == R && nfw == F) return launch_rollout_t<R, F, MODE>(p, n_tiles, st);
     CEM_CASE(1, 1) CEM_CASE(2, 1) CEM_CASE(3, 1) CEM_CASE(4, 1)
     CEM_CASE(1, 2) CEM_CASE(2, 2) CEM_CASE(3, 2) CEM_CASE(4, 2)
 #undef CEM_CASE
@@ -438,7 +438,7 @@ void fill_rollout_common(const cem_planner *h, RolloutParams &p)
     std::memset(&p, 0, sizeof(p));
     p.wpack = (const f4 *)(ws + l.wpack); p.bias_h = (const float *)(ws + l.bias_h);
     p.bias_mu = (const float *)(ws + l.bias_mu); p.bias_var = (const float *)(ws + l.bias_var);
-    p.nmin = (const float *)(ws + l.nmin); p.ndelta = (const float *)(ws + l.ndelta);
+    p.nmin = (const float *)(ws + l.nmin); p.nrdelta = (const float *)(ws + l.ndelta);
     p.ctrl = (const CtrlBlock *)(ws + l.ctrl);
     p.member_stride_f4 = d.member_stride_f4;
     for (int w = 0; w < 4; ++w) { p.wave_off_f4[w] = d.wave_off_f4[w]; p.wave_groups[w] = (uint32_t)d.wave_groups[w]; }
@@ -482,7 +482,8 @@ int enqueue_rollout(cem_planner *h, int it)
     rp.H = d.H; rp.Bloc = d.Bloc; rp.Btot = d.Btot; rp.it = it; rp.variant = h->cfg.variant; rp.check_done = 1;
     size_t e0 = 0;
     if (h->timing) { e0 = h->ev_kind.size() * 2; h->ev_kind.push_back({(int)e0, 0}); hipEventRecord(get_event(h, e0), h->stream); }
-    HIPCHK(launch_rollout<false>(h->rc, d.NFW, rp, h->n_tiles, h->stream));
+    if (rp.eps_model) HIPCHK(launch_rollout<1>(h->rc, d.NFW, rp, h->n_tiles, h->stream));
+    else HIPCHK(launch_rollout<0>(h->rc, d.NFW, rp, h->n_tiles, h->stream));
     if (h->timing) hipEventRecord(get_event(h, e0 + 1), h->stream);
 
     ReduceParams qp{}; qp.ret = rp.ret; qp.costs = rp.costs; qp.scores = (float *)(ws + l.scores_local); qp.ctrl = sp.ctrl;
@@ -656,7 +657,7 @@ int cem_unfold_sequences(cem_planner_t *h, const float *s0_dev, const float *act
     rp.tiles = dt; rp.s0 = s0_dev; rp.actions = actions_dev; rp.eps_model = eps_model_dev; rp.ret = ret; rp.costs = nullptr;
     rp.traj = traj_out_dev; rp.mu_out = mu_out_dev; rp.sd_out = sd_out_dev;
     rp.H = horizon; rp.Bloc = n_rows; rp.Btot = n_rows; rp.it = 0; rp.variant = 0; rp.check_done = 0;
-    hipError_t e = launch_rollout<true>(rc, d.NFW, rp, (int)tiles.size(), h->stream);
+    hipError_t e = launch_rollout<1>(rc, d.NFW, rp, (int)tiles.size(), h->stream);
     hipError_t e2 = hipStreamSynchronize(h->stream);
     hipFree(dt); hipFree(ret);
     HIPCHK(e); HIPCHK(e2);

@@ -67,7 +67,7 @@ struct RolloutParams {
     const float *bias_mu;        // [E][128] zero padded
     const float *bias_var;       // [E][128]
     const float *nmin;           // [128] scale(): inputs_min, 0 on padding
-    const float *ndelta;         // [128] scale(): delta (1.01 rule applied), 1 on padding
+    const float *nrdelta;        // [128] scale(): 1/delta (1.01 rule applied), 1 on padding
     const float *s0;             // [O] broadcast or [B][O]
     const float *actions;        // [n_act][H][A]
     const float *eps_model;      // nullptr -> Philox; else this iteration's [H][Btot][O]
@@ -107,10 +107,17 @@ __device__ __forceinline__ void philox4x32_10(uint32_t &c0, uint32_t &c1, uint32
     }
 }
 
-__device__ __forceinline__ f4 cem_normal4(uint32_t idx, uint32_t t, uint32_t it, uint32_t sub, uint32_t stream, const CtrlBlock *ctrl)
+struct PhiloxKey { uint32_t k0, k1, c3; };
+
+__device__ __forceinline__ PhiloxKey cem_key(const CtrlBlock *ctrl)
 {
-    uint32_t c0 = idx, c1 = t | (it << 16), c2 = sub | (stream << 16), c3 = ctrl->call_lo;
-    philox4x32_10(c0, c1, c2, c3, ctrl->seed_lo, ctrl->seed_hi ^ ctrl->call_hi);
+    PhiloxKey k; k.k0 = ctrl->seed_lo; k.k1 = ctrl->seed_hi ^ ctrl->call_hi; k.c3 = ctrl->call_lo; return k;
+}
+
+__device__ __forceinline__ f4 cem_normal4(uint32_t idx, uint32_t t, uint32_t it, uint32_t sub, uint32_t stream, const PhiloxKey key)
+{
+    uint32_t c0 = idx, c1 = t | (it << 16), c2 = sub | (stream << 16), c3 = key.c3;
+    philox4x32_10(c0, c1, c2, c3, key.k0, key.k1);
     // 23-bit uniforms in (0,1): ((x>>9)+0.5) * 2^-23 is exact in fp32
     const float u0 = ((float)(c0 >> 9) + 0.5f) * 1.1920928955078125e-07f;
     const float u1 = ((float)(c1 >> 9) + 0.5f) * 1.1920928955078125e-07f;
@@ -127,14 +134,23 @@ __device__ __forceinline__ f4 cem_normal4(uint32_t idx, uint32_t t, uint32_t it,
     return z;
 }
 
-// tf.math.softplus as Eigen evaluates it
+// tf.math.softplus.  Eigen evaluates x (x > 13.94), exp(x) (x < -13.94), log1p(exp(x)) otherwise;
+// all three branches are the one function max(x,0) + log1p(exp(-|x|)) to within 1e-6 relative, computed here
+// branch-free: t = exp(-|x|) on v_exp_f32, log1p(t) = 2 atanh(t/(2+t)) as an odd series in z = t/(2+t) <= 1/3
+// (truncation < 2e-8).  Measured against the fp64 oracle in tests/test_gpu_parity.py.
 __device__ __forceinline__ float cem_softplus(float x)
 {
-    const float thr = -13.942383766174316f;   // fl32(log(eps_f32) + 2)
-    if (x > -thr) return x;
-    const float ex = expf(x);
-    if (x < thr) return ex;
-    return log1pf(ex);
+    const float t = __builtin_amdgcn_exp2f(-1.4426950408889634f * __builtin_fabsf(x));
+    const float z = t * __builtin_amdgcn_rcpf(2.0f + t);
+    const float z2 = z * z;
+    float q = 0.07692307692307693f;                       // 1/13
+    q = __builtin_fmaf(q, z2, 0.09090909090909091f);      // 1/11
+    q = __builtin_fmaf(q, z2, 0.1111111111111111f);
+    q = __builtin_fmaf(q, z2, 0.14285714285714285f);
+    q = __builtin_fmaf(q, z2, 0.2f);
+    q = __builtin_fmaf(q, z2, 0.3333333333333333f);
+    q = __builtin_fmaf(q, z2, 1.0f);
+    return __builtin_fmaf(2.0f * z, q, fmaxf(x, 0.f));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -142,50 +158,61 @@ __device__ __forceinline__ float cem_softplus(float x)
 // ---------------------------------------------------------------------------------------------------------
 struct AGroup { f4 a, b; };
 
-struct WQueue {              // 3-deep register prefetch queue over this wave's linear weight stream
+// Weight prefetch ring: 4 register slots over this wave's linear weight stream, always 3 groups ahead of the
+// MFMAs.  Every stage consumes a multiple of 4 groups (layer 0 is zero-padded to 4*NFW groups on the host), so the
+// slot of stage-local group F is the compile-time constant F & 3: no register moves, no branches.
+struct WRing {
     const f4 *base;
     int n, pos;
-    AGroup q0, q1, q2;
+    AGroup slot[4];
     __device__ __forceinline__ AGroup ld(int g) const { AGroup r; r.a = base[g * 128]; r.b = base[g * 128 + 64]; return r; }
-    __device__ __forceinline__ void init(const f4 *b, int n_) { base = b; n = n_; q0 = ld(0); q1 = ld(1 % n_); q2 = ld(2 % n_); pos = 3 % n_; }
-    __device__ __forceinline__ AGroup pop() { AGroup r = q0; q0 = q1; q1 = q2; q2 = ld(pos); pos = (pos + 1 == n) ? 0 : pos + 1; return r; }
+    __device__ __forceinline__ void init(const f4 *b, int n_)
+    {
+        base = b; n = n_;
+        slot[0] = ld(0); slot[1] = ld(1 % n_); slot[2] = ld(2 % n_); slot[3] = slot[2];
+        pos = 3 % n_;
+    }
 };
 
 #define CEM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-template <int RC>
-__device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], const f4 (&hB)[CEM_NG][RC], WQueue &wq, const int kf)
+template <int RC, int KF>
+__device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], const f4 (&hB)[CEM_NG][RC], WRing &wq)
 {
+    static_assert(KF % 4 == 0, "stage lengths must keep the ring phase");
 #pragma unroll
-    for (int F = 0; F < CEM_NG; ++F) {
-        if (F < kf) {                       // wave-uniform
-            const AGroup g = wq.pop();
+    for (int F = 0; F < KF; ++F) {
+        wq.slot[(F + 3) & 3] = wq.ld(wq.pos);            // group F+3 of this stage (or the next stage's first groups)
+        wq.pos = (wq.pos + 1 == wq.n) ? 0 : wq.pos + 1;
+        // pin the prefetch here: unpinned, the machine scheduler sinks the load to just before its use and every
+        // group of MFMAs eats a full L2 round trip
+        __builtin_amdgcn_sched_barrier(0);
+        const AGroup g = wq.slot[F & 3];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                for (int c = 0; c < RC; ++c) {
-                    acc0[c] = CEM_MFMA(g.a[r], hB[F][c][r], acc0[c]);
-                    acc1[c] = CEM_MFMA(g.b[r], hB[F][c][r], acc1[c]);
-                }
+            for (int c = 0; c < RC; ++c) {
+                acc0[c] = CEM_MFMA(g.a[r], hB[F][c][r], acc0[c]);
+                acc1[c] = CEM_MFMA(g.b[r], hB[F][c][r], acc1[c]);
             }
         }
     }
 }
 
-template <int RC>
-__device__ __forceinline__ void cem_read_x(f4 (&hB)[CEM_NG][RC], const char *smem, const int xoff, const int lane, const int nblk)
+template <int RC, int NB>
+__device__ __forceinline__ void cem_read_x(f4 (&hB)[CEM_NG][RC], const char *smem, const int xoff, const int lane)
 {
 #pragma unroll
-    for (int F = 0; F < CEM_NG; ++F) {
-        if (F < nblk) {
+    for (int F = 0; F < NB; ++F) {
 #pragma unroll
-            for (int c = 0; c < RC; ++c)
-                hB[F][c] = *reinterpret_cast<const f4 *>(smem + xoff + ((c * CEM_NG + F) * 64 + lane) * 16);
-        }
+        for (int c = 0; c < RC; ++c)
+            hB[F][c] = *reinterpret_cast<const f4 *>(smem + xoff + ((c * CEM_NG + F) * 64 + lane) * 16);
     }
 }
 
-template <int RC, int NFW, bool DEBUG>
+// MODE 0: the planner's hot path (Philox noise, no debug outputs).  MODE 1: general path — explicit eps_model
+// tensors (parity mode) and/or the trajectory / head-moment outputs of cem_unfold_sequences.
+template <int RC, int NFW, int MODE>
 __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -200,8 +227,9 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
     constexpr int XB = RC * CEM_NG * 1024;
     float *part = reinterpret_cast<float *>(smem + 2 * XB);
     int xw = 0;                                          // buffer the next stage writes
+    const PhiloxKey key = cem_key(p.ctrl);
 
-    WQueue wq;
+    WRing wq;
     wq.init(p.wpack + (size_t)td.member * p.member_stride_f4 + p.wave_off_f4[w] + lane, (int)p.wave_groups[w]);
 
     const float *bias_h = p.bias_h + (size_t)td.member * p.L * CEM_U;
@@ -244,8 +272,8 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
                 for (int c = 0; c < RC; ++c) { acc0[c] = (f4){0.f, 0.f, 0.f, 0.f}; acc1[c] = (f4){0.f, 0.f, 0.f, 0.f}; }
                 const f4 b0 = *reinterpret_cast<const f4 *>(bias_h + l * CEM_U + 16 * (2 * w) + 4 * q);
                 const f4 b1 = *reinterpret_cast<const f4 *>(bias_h + l * CEM_U + 16 * (2 * w + 1) + 4 * q);
-                if (l == 0) cem_mfma_stage<RC>(acc0, acc1, hB, wq, p.KB_in);
-                else cem_mfma_stage<RC>(acc0, acc1, hB, wq, CEM_NG);
+                if (l == 0) cem_mfma_stage<RC, 4 * NFW>(acc0, acc1, hB, wq);
+                else cem_mfma_stage<RC, CEM_NG>(acc0, acc1, hB, wq);
 #pragma unroll
                 for (int c = 0; c < RC; ++c) {
                     f4 h0 = acc0[c] + b0, h1 = acc1[c] + b1;
@@ -255,7 +283,7 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
                     *reinterpret_cast<f4 *>(smem + xw + ((c * CEM_NG + 2 * w + 1) * 64 + lane) * 16) = h1;
                 }
                 __syncthreads();
-                cem_read_x<RC>(hB, smem, xw, lane, CEM_NG);
+                cem_read_x<RC, CEM_NG>(hB, smem, xw, lane);
                 xw ^= XB;
             }
         }
@@ -271,46 +299,77 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
 
 #pragma unroll
         for (int i = 0; i < NFW; ++i) {
-            const int Fo = w + 4 * i;
-            if (Fo < p.KB_in) {
+            const int Fo = w + 4 * i;                  // < 4*NFW: every such block is an input block (zero padded)
+            {
                 const bool heads = (t >= 0) && (Fo < p.KB_obs);
                 const int f0 = 16 * Fo + 4 * q;
+                // everything the epilogue needs from memory is requested BEFORE the MFMA stage
                 const f4 mn4 = *reinterpret_cast<const f4 *>(p.nmin + f0);
-                const f4 dl4 = *reinterpret_cast<const f4 *>(p.ndelta + f0);
-                f4 accm[RC], accv[RC];
-#pragma unroll
-                for (int c = 0; c < RC; ++c) { accm[c] = (f4){0.f, 0.f, 0.f, 0.f}; accv[c] = (f4){0.f, 0.f, 0.f, 0.f}; }
+                const f4 rd4 = *reinterpret_cast<const f4 *>(p.nrdelta + f0);
                 f4 bm = (f4){0.f, 0.f, 0.f, 0.f}, bv = (f4){0.f, 0.f, 0.f, 0.f};
                 if (heads) {
                     bm = *reinterpret_cast<const f4 *>(bias_mu + f0);
                     bv = *reinterpret_cast<const f4 *>(bias_var + f0);
-                    cem_mfma_stage<RC>(accm, accv, hB, wq, CEM_NG);
                 }
+                f4 act4[RC];
+                const bool blk_act = (16 * Fo + 16 > O) && (16 * Fo < O + A);          // wave-uniform
+#pragma unroll
+                for (int c = 0; c < RC; ++c) {
+                    act4[c] = (f4){0.f, 0.f, 0.f, 0.f};
+                    if (blk_act) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            int af = f0 + r - O; af = af < 0 ? 0 : (af >= A ? A - 1 : af);
+                            act4[c][r] = p.actions[((size_t)(td.act_base + slotc[c]) * H + tn) * A + af];
+                        }
+                    }
+                }
+                f4 eps4[RC];
+#pragma unroll
+                for (int c = 0; c < RC; ++c) eps4[c] = (f4){0.f, 0.f, 0.f, 0.f};
+                if (heads && p.sampling) {
+#pragma unroll
+                    for (int c = 0; c < RC; ++c) {
+                        if (MODE == 1 && p.eps_model) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int fc = (f0 + r < O) ? f0 + r : O - 1;
+                                eps4[c][r] = p.eps_model[((size_t)t * p.Btot + td.noise_row_base + slotc[c]) * O + fc];
+                            }
+                        } else {
+                            eps4[c] = cem_normal4((uint32_t)(td.noise_row_base + slotc[c]), (uint32_t)t, (uint32_t)p.it,
+                                                  (uint32_t)(4 * Fo + q), CEM_STREAM_MODEL, key);
+                        }
+                    }
+                }
+                f4 accm[RC], accv[RC];
+#pragma unroll
+                for (int c = 0; c < RC; ++c) { accm[c] = (f4){0.f, 0.f, 0.f, 0.f}; accv[c] = (f4){0.f, 0.f, 0.f, 0.f}; }
+                if (heads) cem_mfma_stage<RC, CEM_NG>(accm, accv, hB, wq);
+
+                // which scorer kinds have features in this 16-feature block (wave-uniform)
+                const int blo = 16 * Fo, bhi = 16 * Fo + 16;
+                const bool blk_goal = p.sc.goal_mode ? (p.sc.goal_lo >= blo && p.sc.goal_lo < bhi) : (p.sc.goal_lo < bhi && p.sc.goal_hi > blo);
+                bool blk_cost = false;
+#pragma unroll
+                for (int k = 1; k < CEM_NKIND; ++k)
+                    if (k < nk) blk_cost = blk_cost || (p.sc.cost_lo[k - 1] < bhi && p.sc.cost_hi[k - 1] > blo);
+
 #pragma unroll
                 for (int c = 0; c < RC; ++c) {
                     const int slot = 16 * c + j;
                     const bool valid = slot < td.cnt;
                     f4 sn = s[i][c];
                     if (heads) {
-                        f4 eps = (f4){0.f, 0.f, 0.f, 0.f};
-                        if (p.sampling) {
-                            if (p.eps_model) {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    if (f0 + r < O) eps[r] = p.eps_model[((size_t)t * p.Btot + td.noise_row_base + slotc[c]) * O + f0 + r];
-                            } else {
-                                eps = cem_normal4((uint32_t)(td.noise_row_base + slotc[c]), (uint32_t)t, (uint32_t)p.it, (uint32_t)(4 * Fo + q), CEM_STREAM_MODEL, p.ctrl);
-                            }
-                        }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int f = f0 + r;
                             const float mu = accm[c][r] + bm[r];
                             const float var = cem_softplus(accv[c][r] + bv[r]) + 1e-4f;
-                            const float sd = sqrtf(var);
-                            const float d = p.sampling ? mu + sd * eps[r] : mu;      // Normal.sample = loc + scale*eps
-                            if (f < O) sn[r] = sn[r] + d;                            // s_t += d_s_t
-                            if (DEBUG) {
+                            const float sd = __builtin_amdgcn_sqrtf(var);
+                            const float d = p.sampling ? mu + sd * eps4[c][r] : mu;   // Normal.sample = loc + scale*eps
+                            sn[r] = (f < O) ? sn[r] + d : sn[r];                      // s_t += d_s_t
+                            if (MODE == 1) {
                                 if (valid && f < O) {
                                     const size_t o = ((size_t)(td.row_base + slot) * H + t) * O + f;
                                     if (p.mu_out) p.mu_out[o] = mu;
@@ -320,7 +379,7 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
                         }
                         s[i][c] = sn;
                     }
-                    if (DEBUG) {
+                    if (MODE == 1) {
                         if (p.traj && valid) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
@@ -328,30 +387,34 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
                         }
                     }
                     // closest_distance terms of the lidar features this lane holds
+                    if (blk_goal || blk_cost) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int f = f0 + r;
-                        const float lid = fminf(fmaxf(p.sc.D - p.sc.D * (1.0f - sn[r]), 0.f), p.sc.D);
-                        const float gv = p.sc.goal_mode ? fmaxf(sn[r], 0.f) : lid;
-                        const bool ing = p.sc.goal_mode ? (f == p.sc.goal_lo) : (f >= p.sc.goal_lo && f < p.sc.goal_hi);
-                        pm[0][c] = ing ? fminf(pm[0][c], gv) : pm[0][c];
+                        for (int r = 0; r < 4; ++r) {
+                            const int f = f0 + r;
+                            const float lid = fminf(fmaxf(p.sc.D - p.sc.D * (1.0f - sn[r]), 0.f), p.sc.D);
+                            if (blk_goal) {
+                                const float gv = p.sc.goal_mode ? fmaxf(sn[r], 0.f) : lid;
+                                const bool ing = p.sc.goal_mode ? (f == p.sc.goal_lo) : (f >= p.sc.goal_lo && f < p.sc.goal_hi);
+                                pm[0][c] = ing ? fminf(pm[0][c], gv) : pm[0][c];
+                            }
+                            if (blk_cost) {
 #pragma unroll
-                        for (int k = 1; k < CEM_NKIND; ++k) {
-                            if (k < nk) {
-                                const bool in = f >= p.sc.cost_lo[k - 1] && f < p.sc.cost_hi[k - 1];
-                                pm[k][c] = in ? fminf(pm[k][c], lid) : pm[k][c];
+                                for (int k = 1; k < CEM_NKIND; ++k) {
+                                    if (k < nk) {
+                                        const bool in = f >= p.sc.cost_lo[k - 1] && f < p.sc.cost_hi[k - 1];
+                                        pm[k][c] = in ? fminf(pm[k][c], lid) : pm[k][c];
+                                    }
+                                }
                             }
                         }
                     }
-                    // next scaled input x = (concat[s, a] - min) / delta
+                    // next scaled input x = (concat[s, a] - min) * (1/delta)
                     f4 x;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int f = f0 + r;
-                        float xv = 0.f;
-                        if (f < O) xv = sn[r];
-                        else if (f < O + A) xv = p.actions[((size_t)(td.act_base + slotc[c]) * H + tn) * A + (f - O)];
-                        x[r] = (xv - mn4[r]) / dl4[r];
+                        const float xv = (f < O) ? sn[r] : ((f < O + A) ? act4[c][r] : 0.f);
+                        x[r] = (xv - mn4[r]) * rd4[r];
                     }
                     *reinterpret_cast<f4 *>(smem + xw + ((c * CEM_NG + Fo) * 64 + lane) * 16) = x;
                 }
@@ -401,7 +464,7 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
             d_prev = dn;
             c_prev = cn;
         }
-        cem_read_x<RC>(hB, smem, xw, lane, p.KB_in);
+        cem_read_x<RC, 4 * NFW>(hB, smem, xw, lane);
         xw ^= XB;
     }
     if (w == 0 && lane < td.cnt) p.ret[td.row_base + lane] = cum;
@@ -435,7 +498,7 @@ __global__ __launch_bounds__(256) void cem_sample_kernel(const SampleParams p)
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int z = idx % AZ, t = (idx / AZ) % p.H, n = idx / (AZ * p.H);
         f4 e = (f4){0.f, 0.f, 0.f, 0.f};
-        if (!p.eps_act) e = cem_normal4((uint32_t)n, (uint32_t)t, (uint32_t)p.it, (uint32_t)z, CEM_STREAM_ACT, p.ctrl);
+        if (!p.eps_act) e = cem_normal4((uint32_t)n, (uint32_t)t, (uint32_t)p.it, (uint32_t)z, CEM_STREAM_ACT, cem_key(p.ctrl));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int a = 4 * z + r;
@@ -646,7 +709,7 @@ __global__ void cem_final_kernel(const FinalParams p)
     if (a < p.A) {
         float eps;
         if (p.eps_out) eps = p.eps_out[a];
-        else { const f4 e = cem_normal4((uint32_t)(a >> 2), 0u, 0u, 0u, CEM_STREAM_OUT, p.ctrl); eps = e[a & 3]; }
+        else { const f4 e = cem_normal4((uint32_t)(a >> 2), 0u, 0u, 0u, CEM_STREAM_OUT, cem_key(p.ctrl)); eps = e[a & 3]; }
         p.result[a] = p.ctrl->best[a] + eps * p.noise_stddev;                                 // cem_mpc.py:68
     }
     if (a == 0) {
@@ -667,7 +730,7 @@ __global__ __launch_bounds__(256) void cem_fill_noise_kernel(const FillParams p)
         const size_t total = (size_t)p.I * p.N * p.H * AZ;
         for (size_t idx = gid; idx < total; idx += gsz) {
             const int z = idx % AZ, t = (idx / AZ) % p.H, n = (idx / ((size_t)AZ * p.H)) % p.N, it = idx / ((size_t)AZ * p.H * p.N);
-            const f4 e = cem_normal4((uint32_t)n, (uint32_t)t, (uint32_t)it, (uint32_t)z, CEM_STREAM_ACT, p.ctrl);
+            const f4 e = cem_normal4((uint32_t)n, (uint32_t)t, (uint32_t)it, (uint32_t)z, CEM_STREAM_ACT, cem_key(p.ctrl));
             for (int r = 0; r < 4; ++r) if (4 * z + r < p.A) p.eps_act[(((size_t)it * p.N + n) * p.H + t) * p.A + 4 * z + r] = e[r];
         }
     }
@@ -676,12 +739,12 @@ __global__ __launch_bounds__(256) void cem_fill_noise_kernel(const FillParams p)
         const size_t total = (size_t)p.I * p.H * p.B * OZ;
         for (size_t idx = gid; idx < total; idx += gsz) {
             const int fq = idx % OZ; const size_t row = (idx / OZ) % p.B; const int t = (idx / ((size_t)OZ * p.B)) % p.H, it = idx / ((size_t)OZ * p.B * p.H);
-            const f4 e = cem_normal4((uint32_t)row, (uint32_t)t, (uint32_t)it, (uint32_t)fq, CEM_STREAM_MODEL, p.ctrl);
+            const f4 e = cem_normal4((uint32_t)row, (uint32_t)t, (uint32_t)it, (uint32_t)fq, CEM_STREAM_MODEL, cem_key(p.ctrl));
             for (int r = 0; r < 4; ++r) if (4 * fq + r < p.O) p.eps_model[(((size_t)it * p.H + t) * p.B + row) * p.O + 4 * fq + r] = e[r];
         }
     }
     if (p.eps_out && gid < (size_t)p.A) {
-        const f4 e = cem_normal4((uint32_t)(gid >> 2), 0u, 0u, 0u, CEM_STREAM_OUT, p.ctrl);
+        const f4 e = cem_normal4((uint32_t)(gid >> 2), 0u, 0u, 0u, CEM_STREAM_OUT, cem_key(p.ctrl));
         p.eps_out[gid] = e[gid & 3];
     }
 }

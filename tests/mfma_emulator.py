@@ -67,7 +67,7 @@ class TileEmulator:
         # input image: X[c][F][lane=(q,j)][r] = x[16c + j][16F + 4q + r]
         X = np.zeros((rc, 8, 64, 4))
         for c in range(rc):
-            for F in range(d['KB_in']):
+            for F in range(d['KF0']):
                 for lane in range(64):
                     q, j = lane >> 4, lane & 15
                     for r in range(4):
@@ -75,7 +75,7 @@ class TileEmulator:
                         X[c, F, lane, r] = x_rows[16 * c + j, f] if f < Din else 0.0
         hidden = []
         for l in range(d['L']):
-            outs = self.stage(X, d['KB_in'] if l == 0 else 8, rc)
+            outs = self.stage(X, d['KF0'] if l == 0 else 8, rc)
             Xn = np.zeros((rc, 8, 64, 4))
             for w in range(4):
                 for g in range(2):
@@ -128,11 +128,12 @@ def dims_of(obs_dim, act_dim, n_layers):
     Din = obs_dim + act_dim
     KB_in, KB_obs = (Din + 15) // 16, (obs_dim + 15) // 16
     NFW = (KB_in + 3) // 4
+    KF0 = 4 * NFW                      # layer-0 groups per wave, zero padded (ring phase)
     groups, offs, off = [], [], 0
     for w in range(4):
-        g = KB_in + 8 * (n_layers - 1) + 8 * sum(1 for i in range(NFW) if w + 4 * i < KB_obs)
+        g = KF0 + 8 * (n_layers - 1) + 8 * sum(1 for i in range(NFW) if w + 4 * i < KB_obs)
         groups.append(g)
         offs.append(off)
         off += g * 128
-    return dict(O=obs_dim, A=act_dim, L=n_layers, KB_in=KB_in, KB_obs=KB_obs, NFW=NFW, wave_groups=groups,
+    return dict(O=obs_dim, A=act_dim, L=n_layers, KB_in=KB_in, KB_obs=KB_obs, NFW=NFW, KF0=KF0, wave_groups=groups,
                 wave_off_f4=offs, member_stride_f4=off + 256)
