@@ -267,16 +267,17 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
         if (t >= 0) {
             // ---- hidden layers: h = relu(h W + b)  (mlp_ensemble.py:18-22) -----------------------------
             for (int l = 0; l < p.L; ++l) {
-                f4 acc0[RC], acc1[RC];
-#pragma unroll
-                for (int c = 0; c < RC; ++c) { acc0[c] = (f4){0.f, 0.f, 0.f, 0.f}; acc1[c] = (f4){0.f, 0.f, 0.f, 0.f}; }
+                // the accumulators start at the bias (x W + b with b added first: same sum, one rounding order apart)
                 const f4 b0 = *reinterpret_cast<const f4 *>(bias_h + l * CEM_U + 16 * (2 * w) + 4 * q);
                 const f4 b1 = *reinterpret_cast<const f4 *>(bias_h + l * CEM_U + 16 * (2 * w + 1) + 4 * q);
+                f4 acc0[RC], acc1[RC];
+#pragma unroll
+                for (int c = 0; c < RC; ++c) { acc0[c] = b0; acc1[c] = b1; }
                 if (l == 0) cem_mfma_stage<RC, 4 * NFW>(acc0, acc1, hB, wq);
                 else cem_mfma_stage<RC, CEM_NG>(acc0, acc1, hB, wq);
 #pragma unroll
                 for (int c = 0; c < RC; ++c) {
-                    f4 h0 = acc0[c] + b0, h1 = acc1[c] + b1;
+                    f4 h0 = acc0[c], h1 = acc1[c];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { h0[r] = fmaxf(h0[r], 0.f); h1[r] = fmaxf(h1[r], 0.f); }
                     *reinterpret_cast<f4 *>(smem + xw + ((c * CEM_NG + 2 * w) * 64 + lane) * 16) = h0;
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
                 }
                 f4 accm[RC], accv[RC];
 #pragma unroll
-                for (int c = 0; c < RC; ++c) { accm[c] = (f4){0.f, 0.f, 0.f, 0.f}; accv[c] = (f4){0.f, 0.f, 0.f, 0.f}; }
+                for (int c = 0; c < RC; ++c) { accm[c] = bm; accv[c] = bv; }
                 if (heads) cem_mfma_stage<RC, CEM_NG>(accm, accv, hB, wq);
 
                 // which scorer kinds have features in this 16-feature block (wave-uniform)
@@ -364,8 +365,8 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int f = f0 + r;
-                            const float mu = accm[c][r] + bm[r];
-                            const float var = cem_softplus(accv[c][r] + bv[r]) + 1e-4f;
+                            const float mu = accm[c][r];
+                            const float var = cem_softplus(accv[c][r]) + 1e-4f;
                             const float sd = __builtin_amdgcn_sqrtf(var);
                             const float d = p.sampling ? mu + sd * eps4[c][r] : mu;   // Normal.sample = loc + scale*eps
                             sn[r] = (f < O) ? sn[r] + d : sn[r];                      // s_t += d_s_t
