@@ -14,7 +14,7 @@ CEM_MAX_ACT = 32
 CEM_MAX_COST_KINDS = 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libcem_mpc_gfx950.so')
+LIB_PATH = os.environ.get('CEM_MPC_LIB') or os.path.join(_HERE, 'lib', 'libcem_mpc_gfx950.so')   # env override: A/B builds
 
 EXPORTED_SYMBOLS = [
     'cem_abi_version', 'cem_status_string', 'cem_last_hip_error', 'cem_weight_blob_floats',

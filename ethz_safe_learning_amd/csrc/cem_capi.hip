@@ -170,7 +170,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
     size_t ctrl, musig, scores_local, scores_global, actions, elite, returns, costs, result, wpack, bias_h, bias_mu, bias_var,
-        nmin, ndelta, tiles, eps_out, total;
+        nmin, ndelta, omask, kind_sel, tiles, eps_out, total;
 };
 
 Layout make_layout(const cem_config_t *c, const Dims &d, size_t max_tiles)
@@ -192,6 +192,8 @@ Layout make_layout(const cem_config_t *c, const Dims &d, size_t max_tiles)
     l.bias_var = take((size_t)d.E * CEM_U * 4);
     l.nmin = take(CEM_U * 4);
     l.ndelta = take(CEM_U * 4);
+    l.omask = take(2 * CEM_U * 4);
+    l.kind_sel = take(CEM_NKIND * CEM_U * 4);
     l.tiles = take(max_tiles * sizeof(TileDesc));
     l.eps_out = take(CEM_MAX_ACT * 4);
     l.total = o;
@@ -334,6 +336,22 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
     h->n_tiles = (int)tiles.size();
     if (hipMemcpyAsync(h->ws + h->lay.tiles, tiles.data(), tiles.size() * sizeof(Tile6), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
         hipStreamSynchronize(h->stream) != hipSuccess) { g_last_hip = (int)hipGetLastError(); hipHostFree(h->h_ctrl); hipHostFree(h->h_result); delete h; return CEM_ERR_HIP; }
+    {   // per-feature predicate tables of the rollout epilogue
+        const Dims &d = h->d;
+        std::vector<float> om(2 * CEM_U, 0.f), ks(CEM_NKIND * CEM_U, std::numeric_limits<float>::infinity());
+        const float ninf = -std::numeric_limits<float>::infinity();
+        for (int f = 0; f < CEM_U; ++f) {
+            om[f] = f < d.O ? 1.f : 0.f;
+            om[CEM_U + f] = (f >= d.O && f < d.O + d.A) ? 1.f : 0.f;
+            const int ghi = s.goal_mode ? s.goal_lo + 1 : s.goal_hi;
+            if (f >= s.goal_lo && f < ghi && f < d.O) ks[f] = ninf;
+            for (int k = 0; k < s.n_cost_kinds; ++k)
+                if (f >= s.cost_lo[k] && f < s.cost_hi[k] && f < d.O) ks[(k + 1) * CEM_U + f] = ninf;
+        }
+        hipMemcpyAsync(h->ws + h->lay.omask, om.data(), om.size() * 4, hipMemcpyHostToDevice, h->stream);
+        hipMemcpyAsync(h->ws + h->lay.kind_sel, ks.data(), ks.size() * 4, hipMemcpyHostToDevice, h->stream);
+        hipStreamSynchronize(h->stream);
+    }
     // identity normaliser until set_normaliser is called
     std::vector<float> mn(CEM_U, 0.f), dl(CEM_U, 1.f);
     hipMemcpyAsync(h->ws + h->lay.nmin, mn.data(), CEM_U * 4, hipMemcpyHostToDevice, h->stream);
@@ -439,6 +457,7 @@ void fill_rollout_common(const cem_planner *h, RolloutParams &p)
     p.wpack = (const f4 *)(ws + l.wpack); p.bias_h = (const float *)(ws + l.bias_h);
     p.bias_mu = (const float *)(ws + l.bias_mu); p.bias_var = (const float *)(ws + l.bias_var);
     p.nmin = (const float *)(ws + l.nmin); p.nrdelta = (const float *)(ws + l.ndelta);
+    p.omask = (const float *)(ws + l.omask); p.kind_sel = (const float *)(ws + l.kind_sel);
     p.ctrl = (const CtrlBlock *)(ws + l.ctrl);
     p.member_stride_f4 = d.member_stride_f4;
     for (int w = 0; w < 4; ++w) { p.wave_off_f4[w] = d.wave_off_f4[w]; p.wave_groups[w] = (uint32_t)d.wave_groups[w]; }

@@ -68,6 +68,8 @@ struct RolloutParams {
     const float *bias_var;       // [E][128]
     const float *nmin;           // [128] scale(): inputs_min, 0 on padding
     const float *nrdelta;        // [128] scale(): 1/delta (1.01 rule applied), 1 on padding
+    const float *omask;          // [2][128] 1.0 on observation features / on action features, else 0
+    const float *kind_sel;       // [CEM_NKIND][128] -inf where the feature belongs to scorer kind k (goal, costs...), +inf elsewhere
     const float *s0;             // [O] broadcast or [B][O]
     const float *actions;        // [n_act][H][A]
     const float *eps_model;      // nullptr -> Philox; else this iteration's [H][Btot][O]
@@ -289,148 +291,129 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
             }
         }
 
-        // ---- heads (mlp_ensemble.py:33-34,189-193), state update (transition_model.py:75), scorer
-        //      partials (safety_gym.py:188-192) and the next scaled input (transition_model.py:70-72,79-87)
+        // ---- heads (mlp_ensemble.py:33-34,189-193), state update (transition_model.py:75), scorer partials
+        //      (safety_gym.py:188-192) and the next scaled input (transition_model.py:70-72,79-87).
+        // A lone wave runs this between the MFMA stages, so it is written as ONE branch-free basic block: 4*RC*NFW
+        // independent element chains + RC*NFW Philox chains give the scheduler the ILP to hide VALU / transcendental
+        // latency (with per-chunk uniform branches it ran latency-bound at ~12 cycles per instruction).  Per-lane
+        // predicates come from per-feature float tables (omask, kind_sel), not from lane-mask SGPR pairs.
         float pm[CEM_NKIND][RC];
 #pragma unroll
         for (int k = 0; k < CEM_NKIND; ++k)
 #pragma unroll
             for (int c = 0; c < RC; ++c) pm[k][c] = __builtin_inff();
         const int tn = (t + 1 < H) ? t + 1 : H - 1;
+        const float live = (t >= 0) ? 1.0f : 0.0f;          // prologue: no heads, the "update" adds exactly 0
+        const float sampling = p.sampling ? 1.0f : 0.0f;
+        const float goalm = p.sc.goal_mode ? 1.0f : 0.0f;
 
 #pragma unroll
         for (int i = 0; i < NFW; ++i) {
             const int Fo = w + 4 * i;                  // < 4*NFW: every such block is an input block (zero padded)
-            {
-                const bool heads = (t >= 0) && (Fo < p.KB_obs);
-                const int f0 = 16 * Fo + 4 * q;
-                // everything the epilogue needs from memory is requested BEFORE the MFMA stage
-                const f4 mn4 = *reinterpret_cast<const f4 *>(p.nmin + f0);
-                const f4 rd4 = *reinterpret_cast<const f4 *>(p.nrdelta + f0);
-                f4 bm = (f4){0.f, 0.f, 0.f, 0.f}, bv = (f4){0.f, 0.f, 0.f, 0.f};
-                if (heads) {
-                    bm = *reinterpret_cast<const f4 *>(bias_mu + f0);
-                    bv = *reinterpret_cast<const f4 *>(bias_var + f0);
+            const int f0 = 16 * Fo + 4 * q;
+            // everything the epilogue needs from memory is requested BEFORE the MFMA stage
+            const f4 mn4 = *reinterpret_cast<const f4 *>(p.nmin + f0);
+            const f4 rd4 = *reinterpret_cast<const f4 *>(p.nrdelta + f0);
+            const f4 bm = *reinterpret_cast<const f4 *>(bias_mu + f0);
+            const f4 bv = *reinterpret_cast<const f4 *>(bias_var + f0);
+            const f4 om4 = *reinterpret_cast<const f4 *>(p.omask + f0) * live;                 // 1 on observation features
+            const f4 isact4 = *reinterpret_cast<const f4 *>(p.omask + CEM_U + f0);            // 1 on action features
+            const f4 sel0 = *reinterpret_cast<const f4 *>(p.kind_sel + f0);                    // -inf on goal features, +inf elsewhere
+            const f4 sel1 = *reinterpret_cast<const f4 *>(p.kind_sel + CEM_U + f0);            // first cost kind
+            f4 act4[RC], eps4[RC];
+#pragma unroll
+            for (int c = 0; c < RC; ++c) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int af = f0 + r - O; af = af < 0 ? 0 : (af >= A ? A - 1 : af);
+                    act4[c][r] = p.actions[((size_t)(td.act_base + slotc[c]) * H + tn) * A + af];
                 }
-                f4 act4[RC];
-                const bool blk_act = (16 * Fo + 16 > O) && (16 * Fo < O + A);          // wave-uniform
-#pragma unroll
-                for (int c = 0; c < RC; ++c) {
-                    act4[c] = (f4){0.f, 0.f, 0.f, 0.f};
-                    if (blk_act) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            int af = f0 + r - O; af = af < 0 ? 0 : (af >= A ? A - 1 : af);
-                            act4[c][r] = p.actions[((size_t)(td.act_base + slotc[c]) * H + tn) * A + af];
-                        }
-                    }
-                }
-                f4 eps4[RC];
-#pragma unroll
-                for (int c = 0; c < RC; ++c) eps4[c] = (f4){0.f, 0.f, 0.f, 0.f};
-                if (heads && p.sampling) {
-#pragma unroll
-                    for (int c = 0; c < RC; ++c) {
-                        if (MODE == 1 && p.eps_model) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int fc = (f0 + r < O) ? f0 + r : O - 1;
-                                eps4[c][r] = p.eps_model[((size_t)t * p.Btot + td.noise_row_base + slotc[c]) * O + fc];
-                            }
-                        } else {
-                            eps4[c] = cem_normal4((uint32_t)(td.noise_row_base + slotc[c]), (uint32_t)t, (uint32_t)p.it,
-                                                  (uint32_t)(4 * Fo + q), CEM_STREAM_MODEL, key);
-                        }
-                    }
-                }
-                f4 accm[RC], accv[RC];
-#pragma unroll
-                for (int c = 0; c < RC; ++c) { accm[c] = bm; accv[c] = bv; }
-                if (heads) cem_mfma_stage<RC, CEM_NG>(accm, accv, hB, wq);
-
-                // which scorer kinds have features in this 16-feature block (wave-uniform)
-                const int blo = 16 * Fo, bhi = 16 * Fo + 16;
-                const bool blk_goal = p.sc.goal_mode ? (p.sc.goal_lo >= blo && p.sc.goal_lo < bhi) : (p.sc.goal_lo < bhi && p.sc.goal_hi > blo);
-                bool blk_cost = false;
-#pragma unroll
-                for (int k = 1; k < CEM_NKIND; ++k)
-                    if (k < nk) blk_cost = blk_cost || (p.sc.cost_lo[k - 1] < bhi && p.sc.cost_hi[k - 1] > blo);
-
-#pragma unroll
-                for (int c = 0; c < RC; ++c) {
-                    const int slot = 16 * c + j;
-                    const bool valid = slot < td.cnt;
-                    f4 sn = s[i][c];
-                    if (heads) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int f = f0 + r;
-                            const float mu = accm[c][r];
-                            const float var = cem_softplus(accv[c][r]) + 1e-4f;
-                            const float sd = __builtin_amdgcn_sqrtf(var);
-                            const float d = p.sampling ? mu + sd * eps4[c][r] : mu;   // Normal.sample = loc + scale*eps
-                            sn[r] = (f < O) ? sn[r] + d : sn[r];                      // s_t += d_s_t
-                            if (MODE == 1) {
-                                if (valid && f < O) {
-                                    const size_t o = ((size_t)(td.row_base + slot) * H + t) * O + f;
-                                    if (p.mu_out) p.mu_out[o] = mu;
-                                    if (p.sd_out) p.sd_out[o] = sd;
-                                }
-                            }
-                        }
-                        s[i][c] = sn;
-                    }
-                    if (MODE == 1) {
-                        if (p.traj && valid) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                if (f0 + r < O) p.traj[((size_t)(td.row_base + slot) * (H + 1) + (t + 1)) * O + f0 + r] = sn[r];
-                        }
-                    }
-                    // closest_distance terms of the lidar features this lane holds
-                    if (blk_goal || blk_cost) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int f = f0 + r;
-                            const float lid = fminf(fmaxf(p.sc.D - p.sc.D * (1.0f - sn[r]), 0.f), p.sc.D);
-                            if (blk_goal) {
-                                const float gv = p.sc.goal_mode ? fmaxf(sn[r], 0.f) : lid;
-                                const bool ing = p.sc.goal_mode ? (f == p.sc.goal_lo) : (f >= p.sc.goal_lo && f < p.sc.goal_hi);
-                                pm[0][c] = ing ? fminf(pm[0][c], gv) : pm[0][c];
-                            }
-                            if (blk_cost) {
-#pragma unroll
-                                for (int k = 1; k < CEM_NKIND; ++k) {
-                                    if (k < nk) {
-                                        const bool in = f >= p.sc.cost_lo[k - 1] && f < p.sc.cost_hi[k - 1];
-                                        pm[k][c] = in ? fminf(pm[k][c], lid) : pm[k][c];
-                                    }
-                                }
-                            }
-                        }
-                    }
-                    // next scaled input x = (concat[s, a] - min) * (1/delta)
-                    f4 x;
+                if (MODE == 1 && p.eps_model) {
+                    const int tc = t < 0 ? 0 : t;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int f = f0 + r;
-                        const float xv = (f < O) ? sn[r] : ((f < O + A) ? act4[c][r] : 0.f);
-                        x[r] = (xv - mn4[r]) * rd4[r];
+                        const int fc = (f0 + r < O) ? f0 + r : O - 1;
+                        eps4[c][r] = p.eps_model[((size_t)tc * p.Btot + td.noise_row_base + slotc[c]) * O + fc];
                     }
-                    *reinterpret_cast<f4 *>(smem + xw + ((c * CEM_NG + Fo) * 64 + lane) * 16) = x;
+                } else {
+                    eps4[c] = cem_normal4((uint32_t)(td.noise_row_base + slotc[c]), (uint32_t)t, (uint32_t)p.it,
+                                          (uint32_t)(4 * Fo + q), CEM_STREAM_MODEL, key);
+                }
+                eps4[c] = eps4[c] * sampling;
+            }
+            f4 accm[RC], accv[RC];
+#pragma unroll
+            for (int c = 0; c < RC; ++c) { accm[c] = bm; accv[c] = bv; }
+            if (t >= 0 && Fo < p.KB_obs) cem_mfma_stage<RC, CEM_NG>(accm, accv, hB, wq);      // wave-uniform
+
+#pragma unroll
+            for (int c = 0; c < RC; ++c) {
+                f4 sn = s[i][c], x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float mu = accm[c][r];
+                    const float sd = __builtin_amdgcn_sqrtf(cem_softplus(accv[c][r]) + 1e-4f);
+                    const float d = mu + sd * eps4[c][r];                         // Normal.sample = loc + scale*eps
+                    sn[r] = sn[r] + d * om4[r];                                    // s_t += d_s_t on observation features
+                    if (MODE == 1) {
+                        const int slot = 16 * c + j;
+                        if (t >= 0 && slot < td.cnt && f0 + r < O) {
+                            const size_t o = ((size_t)(td.row_base + slot) * H + t) * O + f0 + r;
+                            if (p.mu_out) p.mu_out[o] = mu;
+                            if (p.sd_out) p.sd_out[o] = sd;
+                        }
+                    }
+                    // closest_distance term of this feature, folded into the kinds it belongs to
+                    const float lid = fminf(fmaxf(p.sc.D - p.sc.D * (1.0f - sn[r]), 0.f), p.sc.D);
+                    const float gv = goalm != 0.f ? fmaxf(sn[r], 0.f) : lid;
+                    pm[0][c] = fminf(pm[0][c], fmaxf(gv, sel0[r]));
+                    pm[1][c] = fminf(pm[1][c], fmaxf(lid, sel1[r]));
+                    // next scaled input x = (concat[s, a] - min) * (1/delta); padding features have min 0, 1/delta 1, value 0
+                    const float xv = __builtin_fmaf(isact4[r], act4[c][r], sn[r]);   // s is 0 off the observation features
+                    x[r] = (xv - mn4[r]) * rd4[r];
+                }
+                s[i][c] = sn;
+                if (MODE == 1) {
+                    const int slot = 16 * c + j;
+                    if (p.traj && slot < td.cnt) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (f0 + r < O) p.traj[((size_t)(td.row_base + slot) * (H + 1) + (t + 1)) * O + f0 + r] = sn[r];
+                    }
+                }
+                *reinterpret_cast<f4 *>(smem + xw + ((c * CEM_NG + Fo) * 64 + lane) * 16) = x;
+            }
+        }
+        // cost kinds beyond the first (vases+hazards+pillars+gremlins all constrained): rare, kept out of the main block
+        if (nk > 2) {
+#pragma unroll
+            for (int i = 0; i < NFW; ++i) {
+                const int f0 = 16 * (w + 4 * i) + 4 * q;
+                for (int k = 2; k < nk; ++k) {
+                    const f4 selk = *reinterpret_cast<const f4 *>(p.kind_sel + k * CEM_U + f0);
+#pragma unroll
+                    for (int c = 0; c < RC; ++c)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float lid = fminf(fmaxf(p.sc.D - p.sc.D * (1.0f - s[i][c][r]), 0.f), p.sc.D);
+                            const float v = fminf(pm[k][c], fmaxf(lid, selk[r]));
+                            pm[k][c] = v;
+                        }
                 }
             }
         }
-        // wave-level min over the 4 lane groups that hold different features of the same row
+        // min over the 4 lane rows holding different features of the same batch row: two VALU row swaps (no LDS)
 #pragma unroll
         for (int k = 0; k < CEM_NKIND; ++k) {
-            if (k < nk) {
+            if (k < 2 || k < nk) {
 #pragma unroll
                 for (int c = 0; c < RC; ++c) {
-                    float m = pm[k][c];
-                    m = fminf(m, __shfl_xor(m, 16));
-                    m = fminf(m, __shfl_xor(m, 32));
-                    if (q == 0) part[(k * 4 + w) * 64 + 16 * c + j] = m;
+                    const uint32_t mb = __float_as_uint(pm[k][c]);
+                    const auto r16 = __builtin_amdgcn_permlane16_swap(mb, mb, false, false);
+                    const float m16 = fminf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+                    const uint32_t m16b = __float_as_uint(m16);
+                    const auto r32 = __builtin_amdgcn_permlane32_swap(m16b, m16b, false, false);
+                    part[(k * 4 + w) * 64 + 16 * c + j] = fminf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));   // all 4 rows store the same value
                 }
             }
         }
@@ -551,7 +534,7 @@ struct SelectParams {
 __device__ __forceinline__ uint32_t cem_f2key(float f)
 {
     const uint32_t u = __float_as_uint(f);
-    if (f != f) return 0u;                                   // NaN sorts lowest
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0u;          // NaN sorts lowest (bit test: immune to -fno-honor-nans)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
