@@ -136,6 +136,11 @@ def main():
     avg_ms = roll_ms / max(roll_n, 1)
     achieved = flops_launch / (avg_ms * 1e-3) / 1e12
 
+    traffic = None                 # HBM-side bytes per rollout launch from the committed rocprofv3 TCC passes (same workload)
+    tpath = os.path.join(ROOT, 'profiles', 'traffic_b2.json')
+    if G == 1 and args.n_per_gpu == 2000 and os.path.exists(tpath):
+        traffic = json.load(open(tpath))['hbm_bytes_per_launch']
+
     plans_per_s = args.steps / dt
     b2_equiv = plans_per_s * (N / 2000.0)
     out = {
@@ -148,7 +153,7 @@ def main():
                    'hip_graph': bool(cfg.use_graph), 'parallelism': 'candidates sharded x%d, 1 all-gather of scores/iter' % G},
         'candidate_trajectory_steps_per_s': plans_per_s * I * N * H,
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                     'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
                      'kernel': 'cem_rollout_kernel', 'avg_launch_ms': avg_ms, 'launches_timed': roll_n,
                      'algorithmic_flops_per_launch': flops_launch},
     }

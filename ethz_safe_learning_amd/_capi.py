@@ -54,7 +54,7 @@ class CemConfig(C.Structure):
 
 class CemLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in
-                ('scores_local', 'scores_global', 'actions', 'mu_sigma', 'elite_idx', 'returns', 'costs', 'result', 'total')]
+                ('scores_local', 'scores_global', 'actions', 'mu_sigma', 'elite_idx', 'returns', 'costs', 'result', 'stamps', 'total')]
 
 
 class CemError(RuntimeError):

@@ -170,7 +170,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
     size_t ctrl, musig, scores_local, scores_global, actions, elite, returns, costs, result, wpack, bias_h, bias_mu, bias_var,
-        nmin, ndelta, omask, kind_sel, tiles, eps_out, total;
+        nmin, ndelta, omask, kind_sel, tiles, eps_out, stamps, total;
 };
 
 Layout make_layout(const cem_config_t *c, const Dims &d, size_t max_tiles)
@@ -196,6 +196,7 @@ Layout make_layout(const cem_config_t *c, const Dims &d, size_t max_tiles)
     l.kind_sel = take(CEM_NKIND * CEM_U * 4);
     l.tiles = take(max_tiles * sizeof(TileDesc));
     l.eps_out = take(CEM_MAX_ACT * 4);
+    l.stamps = take(max_tiles * 4 * 8 * sizeof(long long));
     l.total = o;
     (void)c;
     return l;
@@ -379,7 +380,7 @@ int cem_planner_layout(const cem_planner_t *h, cem_layout_t *o)
     if (!h || !o) return CEM_ERR_INVALID_ARG;
     o->scores_local = h->lay.scores_local; o->scores_global = h->lay.scores_global; o->actions = h->lay.actions;
     o->mu_sigma = h->lay.musig; o->elite_idx = h->lay.elite; o->returns = h->lay.returns; o->costs = h->lay.costs;
-    o->result = h->lay.result; o->total = h->lay.total;
+    o->result = h->lay.result; o->stamps = h->lay.stamps; o->total = h->lay.total;
     return CEM_OK;
 }
 
@@ -499,6 +500,7 @@ int enqueue_rollout(cem_planner *h, int it)
     rp.eps_model = h->eps_model ? h->eps_model + (size_t)it * d.H * d.Btot * d.O : nullptr;
     rp.ret = (float *)(ws + l.returns); rp.costs = h->cfg.variant == CEM_VARIANT_SAFE ? (uint8_t *)(ws + l.costs) : nullptr;
     rp.H = d.H; rp.Bloc = d.Bloc; rp.Btot = d.Btot; rp.it = it; rp.variant = h->cfg.variant; rp.check_done = 1;
+    rp.stamps = (long long *)(ws + l.stamps);
     size_t e0 = 0;
     if (h->timing) { e0 = h->ev_kind.size() * 2; h->ev_kind.push_back({(int)e0, 0}); hipEventRecord(get_event(h, e0), h->stream); }
     if (rp.eps_model) HIPCHK(launch_rollout<1>(h->rc, d.NFW, rp, h->n_tiles, h->stream));

@@ -76,7 +76,8 @@ struct RolloutParams {
     const CtrlBlock *ctrl;
     float *ret;                  // [Bloc] done-masked return per row
     uint8_t *costs;              // [H][Bloc] masked cost per step (safe variant) or nullptr
-    float *traj, *mu_out, *sd_out;   // debug outputs (DEBUG instantiation only)
+    float *traj, *mu_out, *sd_out;   // debug outputs (MODE 1 instantiation only)
+    long long *stamps;           // [n_tiles][4 waves][8] cycle stamps, written only by -DCEM_STAMPS diagnostic builds
     uint32_t member_stride_f4;
     uint32_t wave_off_f4[4];
     uint32_t wave_groups[4];
@@ -178,8 +179,16 @@ struct WRing {
 
 #define CEM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+#ifdef CEM_STAMPS_FINE
+#define CEM_FSTAMP(F) do { if (fine_) { __builtin_amdgcn_sched_barrier(0); const long long now_ = (long long)__builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_s_waitcnt(0xC07F); fine_[F] += now_ - *ftprev_; *ftprev_ = now_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define CEM_FSTAMP(F) do { } while (0)
+#endif
+
 template <int RC, int KF>
-__device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], const f4 (&hB)[CEM_NG][RC], WRing &wq)
+__device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], const f4 (&hB)[CEM_NG][RC], WRing &wq,
+                                               long long *fine_ = nullptr, long long *ftprev_ = nullptr)
 {
     static_assert(KF % 4 == 0, "stage lengths must keep the ring phase");
 #pragma unroll
@@ -198,6 +207,7 @@ __device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], c
                 acc1[c] = CEM_MFMA(g.b[r], hB[F][c][r], acc1[c]);
             }
         }
+        CEM_FSTAMP(F);
     }
 }
 
@@ -211,6 +221,13 @@ __device__ __forceinline__ void cem_read_x(f4 (&hB)[CEM_NG][RC], const char *sme
             hB[F][c] = *reinterpret_cast<const f4 *>(smem + xoff + ((c * CEM_NG + F) * 64 + lane) * 16);
     }
 }
+
+#ifdef CEM_STAMPS   // diagnostic build only: where a step's cycles go (never in the timed library)
+#define CEM_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const long long now_ = (long long)__builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_s_waitcnt(0xC07F); st_[i] += now_ - tprev_; tprev_ = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CEM_STAMP(i) do { } while (0)
+#endif
 
 // MODE 0: the planner's hot path (Philox noise, no debug outputs).  MODE 1: general path — explicit eps_model
 // tensors (parity mode) and/or the trajectory / head-moment outputs of cem_unfold_sequences.
@@ -264,6 +281,14 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
     const int nk = 1 + p.sc.n_cost;
 
     f4 hB[CEM_NG][RC];
+#ifdef CEM_STAMPS
+    long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev_ = (long long)__builtin_amdgcn_s_memtime();
+    st_[7] = tprev_;                                     // absolute start (which dispatch round a tile ran in)
+#ifdef CEM_STAMPS_FINE
+    long long fst_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+#endif
 
     for (int t = -1; t < H; ++t) {
         if (t >= 0) {
@@ -288,6 +313,7 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
                 __syncthreads();
                 cem_read_x<RC, CEM_NG>(hB, smem, xw, lane);
                 xw ^= XB;
+                CEM_STAMP(l == 0 ? 0 : 1);
             }
         }
 
@@ -344,7 +370,14 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
             f4 accm[RC], accv[RC];
 #pragma unroll
             for (int c = 0; c < RC; ++c) { accm[c] = bm; accv[c] = bv; }
+            CEM_STAMP(2);
+#ifdef CEM_STAMPS_FINE
+            long long fprev_ = tprev_;
+            if (t >= 0 && Fo < p.KB_obs) cem_mfma_stage<RC, CEM_NG>(accm, accv, hB, wq, fst_, &fprev_);
+#else
             if (t >= 0 && Fo < p.KB_obs) cem_mfma_stage<RC, CEM_NG>(accm, accv, hB, wq);      // wave-uniform
+#endif
+            CEM_STAMP(3);
 
 #pragma unroll
             for (int c = 0; c < RC; ++c) {
@@ -417,7 +450,9 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
                 }
             }
         }
+        CEM_STAMP(4);
         __syncthreads();
+        CEM_STAMP(5);
 
         // ---- reward / cost / done bookkeeping of step t (rows of the tile on wave 0's lanes) ------------
         if (w == 0) {
@@ -450,8 +485,16 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
         }
         cem_read_x<RC, 4 * NFW>(hB, smem, xw, lane);
         xw ^= XB;
+        CEM_STAMP(6);
     }
     if (w == 0 && lane < td.cnt) p.ret[td.row_base + lane] = cum;
+#ifdef CEM_STAMPS
+#ifdef CEM_STAMPS_FINE
+    if (p.stamps && lane == 0) for (int i = 0; i < 8; ++i) p.stamps[((size_t)blockIdx.x * 4 + w) * 8 + i] = fst_[i];
+#else
+    if (p.stamps && lane == 0) for (int i = 0; i < 8; ++i) p.stamps[((size_t)blockIdx.x * 4 + w) * 8 + i] = st_[i];
+#endif
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------

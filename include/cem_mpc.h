@@ -104,6 +104,7 @@ typedef struct cem_layout {
     size_t returns;        /* float [P*N/world] — per-row done-masked return of the last rollout */
     size_t costs;          /* uint8 [H][P*N/world] — per-step masked cost (safe variant) */
     size_t result;         /* float [A] action, float best_score, int32 iters, int32 done */
+    size_t stamps;         /* int64 [tiles][4][8] — cycle stamps of the last rollout; written only by -DCEM_STAMPS diagnostic builds */
     size_t total;
 } cem_layout_t;
 

@@ -1,0 +1,53 @@
+"""The candidate-sharded GPU path end to end on ONE GPU: two ranks (processes) share cuda:0 and exchange scores over
+gloo (RCCL refuses two ranks on one device; the collective call site, stream ordering and buffer views are the same).
+Every rank must return exactly the single-rank plan."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    from tests import helpers as hp
+    from ethz_safe_learning_amd.sharded import ShardedCemDriver
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        pb = hp.make_problem(seed=81)
+        N, H, P, E, k, I = 512, 10, 5, 5, 51, 3
+        _, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, variant='safe', post=0.3, noise=0.02, world_size=world, rank=rank)
+        pl = hp.make_planner(pb, pcfg)
+        drv = ShardedCemDriver(pl, I, world_size=world)
+        res = []
+        for call in range(2):
+            a, s, it = drv.plan(pb['state'], seed=17, call=call)
+            res.append((a, s, it))
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_single_rank():
+    import torch
+    import torch.multiprocessing as mp
+    from tests import helpers as hp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.get_context('spawn').Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    pb = hp.make_problem(seed=81)
+    N, H, P, E, k, I = 512, 10, 5, 5, 51, 3
+    _, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, variant='safe', post=0.3, noise=0.02)
+    pl = hp.make_planner(pb, pcfg)
+    for call in range(2):
+        a, sc, it = pl.plan(pb['state'], seed=17, call=call)
+        for rank in (0, 1):
+            ra, rs, rit = out[rank][call]
+            np.testing.assert_array_equal(ra, a)
+            assert rs == sc and rit == it
