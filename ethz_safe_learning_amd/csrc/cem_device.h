@@ -90,7 +90,8 @@ struct RolloutParams {
 };
 
 // ---------------------------------------------------------------------------------------------------------
-// Philox4x32-10 counter RNG (Salmon et al., SC'11) + Box-Muller.  Counter = (index, t | it<<16,
+// Philox4x32-7 counter RNG (Salmon et al., SC'11: 7 rounds is the fewest that passes BigCrush; every VALU instruction
+// is paid in full next to fp32 MFMAs, and the 3 extra rounds of the -10 variant are 27 of them per draw) + Box-Muller.  Counter = (index, t | it<<16,
 // sub | stream<<16, call_lo), key = (seed_lo, seed_hi ^ call_hi): a pure function of GLOBAL indices, so
 // every rank of a candidate-sharded plan draws bit-identical noise for the same (candidate, particle).
 // ---------------------------------------------------------------------------------------------------------
@@ -98,10 +99,10 @@ struct RolloutParams {
 #define CEM_STREAM_ACT 1u
 #define CEM_STREAM_OUT 2u
 
-__device__ __forceinline__ void philox4x32_10(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t k0, uint32_t k1)
+__device__ __forceinline__ void philox4x32_7(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t k0, uint32_t k1)
 {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < 7; ++r) {
         const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
         const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
@@ -120,7 +121,7 @@ __device__ __forceinline__ PhiloxKey cem_key(const CtrlBlock *ctrl)
 __device__ __forceinline__ f4 cem_normal4(uint32_t idx, uint32_t t, uint32_t it, uint32_t sub, uint32_t stream, const PhiloxKey key)
 {
     uint32_t c0 = idx, c1 = t | (it << 16), c2 = sub | (stream << 16), c3 = key.c3;
-    philox4x32_10(c0, c1, c2, c3, key.k0, key.k1);
+    philox4x32_7(c0, c1, c2, c3, key.k0, key.k1);
     // 23-bit uniforms in (0,1): ((x>>9)+0.5) * 2^-23 is exact in fp32
     const float u0 = ((float)(c0 >> 9) + 0.5f) * 1.1920928955078125e-07f;
     const float u1 = ((float)(c1 >> 9) + 0.5f) * 1.1920928955078125e-07f;
@@ -602,6 +603,7 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char sel_smem[];
     __shared__ uint32_t hist[256];
+    __shared__ uint32_t sfx[256];
     __shared__ uint32_t wsum[17];
     __shared__ uint32_t sh_prefix, sh_need;
     __shared__ float red[1024];
@@ -624,11 +626,21 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
             if ((key & mask) == prefix) atomicAdd(&hist[(key >> (8 * pass)) & 255u], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            uint32_t run = 0; int b = 255;
-            for (; b > 0; --b) { if (run + hist[b] >= need) break; run += hist[b]; }
-            sh_prefix = prefix | ((uint32_t)b << (8 * pass));
-            sh_need = need - run;
+        // suffix counts ge[b] = #keys in bins >= b (Hillis-Steele over the 256 bins), then the one bin with
+        // ge[b] >= need > ge[b+1] is the next byte of the k-th largest key
+        if (tid < 256) sfx[tid] = hist[tid];
+        __syncthreads();
+#pragma unroll
+        for (int d = 1; d < 256; d <<= 1) {
+            uint32_t v = 0;
+            if (tid < 256) v = sfx[tid] + ((tid + d < 256) ? sfx[tid + d] : 0u);
+            __syncthreads();
+            if (tid < 256) sfx[tid] = v;
+            __syncthreads();
+        }
+        if (tid < 256) {
+            const uint32_t ge = sfx[tid], gt = (tid < 255) ? sfx[tid + 1] : 0u;
+            if (ge >= need && gt < need) { sh_prefix = prefix | ((uint32_t)tid << (8 * pass)); sh_need = need - gt; }
         }
         __syncthreads();
         prefix = sh_prefix; need = sh_need; mask |= 0xFFu << (8 * pass);

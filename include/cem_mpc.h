@@ -137,7 +137,7 @@ int cem_planner_set_weights(cem_planner_t *h, const float *blob, size_t n_floats
 int cem_planner_set_normaliser(cem_planner_t *h, const float *inputs_min, const float *inputs_max /* [obs+act] */);
 
 /* CemMpc.generate_action (cem_mpc.py:31-33): state[obs] (host) -> action[act] (host).
- * Noise: Philox4x32-10 keyed (seed, call) when the eps pointers are NULL, otherwise explicit
+ * Noise: Philox4x32-7 keyed (seed, call) when the eps pointers are NULL, otherwise explicit
  * DEVICE tensors eps_act[I][N][H][A], eps_model[I][H][P*N][obs] and HOST eps_out[A]
  * (parity mode: "identical seeds" == identical noise tensors). */
 int cem_planner_plan(cem_planner_t *h, const float *state, uint64_t seed, uint64_t call,
