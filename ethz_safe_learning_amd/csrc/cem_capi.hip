@@ -93,19 +93,23 @@ void pack_member(const Dims &d, const float *nat, float *out)
                 }
             }
         };
-        for (int F = 0; F < d.KF0; ++F) {                         // layer 0 (groups F >= KB_in are all zero)
+        // groups are stored in the order the wave visits them: its own input blocks first (cem_perm_l0 / cem_perm_hidden)
+        for (int P = 0; P < d.KF0; ++P) {                         // layer 0 (blocks >= KB_in are all zero)
+            const int F = cem_perm_l0(w, d.NFW, P);
             emit(nat + no.W[0], d.Din, d.U, d.U, F, 0, 2 * w); emit(nat + no.W[0], d.Din, d.U, d.U, F, 1, 2 * w + 1);
             dst += 512;
         }
         for (int l = 1; l < d.L; ++l)
-            for (int F = 0; F < CEM_NG; ++F) {
+            for (int P = 0; P < CEM_NG; ++P) {
+                const int F = cem_perm_hidden(w, P);
                 emit(nat + no.W[l], d.U, d.U, d.U, F, 0, 2 * w); emit(nat + no.W[l], d.U, d.U, d.U, F, 1, 2 * w + 1);
                 dst += 512;
             }
         for (int i = 0; i < d.NFW; ++i) {
             const int Fo = w + 4 * i;
             if (Fo >= d.KB_obs) continue;
-            for (int F = 0; F < CEM_NG; ++F) {                    // heads: g=0 mu, g=1 var of obs block Fo
+            for (int P = 0; P < CEM_NG; ++P) {                    // heads: g=0 mu, g=1 var of obs block Fo
+                const int F = cem_perm_hidden(w, P);
                 emit(nat + no.Wmu, d.U, d.O, d.O, F, 0, Fo); emit(nat + no.Wvar, d.U, d.O, d.O, F, 1, Fo);
                 dst += 512;
             }

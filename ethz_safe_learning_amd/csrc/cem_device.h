@@ -162,9 +162,26 @@ __device__ __forceinline__ float cem_softplus(float x)
 // ---------------------------------------------------------------------------------------------------------
 struct AGroup { f4 a, b; };
 
+// Per-wave K order: "own blocks first".  The 32 output features a wave computes in one layer are, after ReLU, already
+// in its registers in the B-operand layout of the next layer.  So every stage starts its MFMA chain on the wave's OWN
+// input blocks with no wait at all, and the workgroup barrier + the LDS reads of the other blocks are issued underneath
+// those MFMAs.  The k-blocks of a stage are therefore visited in a per-wave order (phi = 0..KF-1 -> block), and the
+// host packs each wave's weight stream in exactly that order (cem_capi.hip pack_member, same two functions).
+__host__ __device__ inline int cem_perm_hidden(int w, int phi)          // hidden-layer / heads input: own blocks 2w, 2w+1
+{
+    return phi < 2 ? 2 * w + phi : ((phi - 2 < 2 * w) ? phi - 2 : phi);
+}
+__host__ __device__ inline int cem_perm_l0(int w, int nfw, int phi)      // layer-0 input: own blocks w, w+4, ...
+{
+    if (phi < nfw) return w + 4 * phi;
+    int n = phi - nfw;
+    for (int F = 0; F < 4 * nfw; ++F) { if ((F & 3) == w) continue; if (n == 0) return F; --n; }
+    return 0;
+}
+
 // Weight prefetch ring: 4 register slots over this wave's linear weight stream, always 3 groups ahead of the
 // MFMAs.  Every stage consumes a multiple of 4 groups (layer 0 is zero-padded to 4*NFW groups on the host), so the
-// slot of stage-local group F is the compile-time constant F & 3: no register moves, no branches.
+// slot of stage-local group phi is the compile-time constant phi & 3: no register moves, no branches.
 struct WRing {
     const f4 *base;
     int n, pos;
@@ -180,46 +197,40 @@ struct WRing {
 
 #define CEM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-#ifdef CEM_STAMPS_FINE
-#define CEM_FSTAMP(F) do { if (fine_) { __builtin_amdgcn_sched_barrier(0); const long long now_ = (long long)__builtin_amdgcn_s_memtime(); \
-        __builtin_amdgcn_s_waitcnt(0xC07F); fine_[F] += now_ - *ftprev_; *ftprev_ = now_; __builtin_amdgcn_sched_barrier(0); } } while (0)
-#else
-#define CEM_FSTAMP(F) do { } while (0)
-#endif
-
-template <int RC, int KF>
-__device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], const f4 (&hB)[CEM_NG][RC], WRing &wq,
-                                               long long *fine_ = nullptr, long long *ftprev_ = nullptr)
+// One dense stage for this wave: acc{0,1}[c] += W^T-groups . hB.  hB[0..NOWN-1] (the wave's own blocks) are already
+// in registers; if EXCHANGE, the barrier that publishes the other waves' blocks and the LDS reads of hB[NOWN..KF-1]
+// are issued after the first group's MFMAs.  L0IN selects the block permutation (layer-0 input vs hidden input).
+template <int RC, int KF, int NOWN, bool L0IN, bool EXCHANGE>
+__device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], f4 (&hB)[CEM_NG][RC], WRing &wq,
+                                               const char *smem, const int xr, const int lane, const int w)
 {
     static_assert(KF % 4 == 0, "stage lengths must keep the ring phase");
 #pragma unroll
-    for (int F = 0; F < KF; ++F) {
-        wq.slot[(F + 3) & 3] = wq.ld(wq.pos);            // group F+3 of this stage (or the next stage's first groups)
+    for (int P = 0; P < KF; ++P) {
+        wq.slot[(P + 3) & 3] = wq.ld(wq.pos);            // group P+3 of this stage (or the next stage's first groups)
         wq.pos = (wq.pos + 1 == wq.n) ? 0 : wq.pos + 1;
         // pin the prefetch here: unpinned, the machine scheduler sinks the load to just before its use and every
         // group of MFMAs eats a full L2 round trip
         __builtin_amdgcn_sched_barrier(0);
-        const AGroup g = wq.slot[F & 3];
+        if (EXCHANGE && P == 1) {
+            __syncthreads();                              // every wave's blocks of the previous stage are in LDS
+#pragma unroll
+            for (int Q = NOWN; Q < KF; ++Q) {
+                const int F = L0IN ? cem_perm_l0(w, KF / 4, Q) : cem_perm_hidden(w, Q);
+#pragma unroll
+                for (int c = 0; c < RC; ++c)
+                    hB[Q][c] = *reinterpret_cast<const f4 *>(smem + xr + ((c * CEM_NG + F) * 64 + lane) * 16);
+            }
+        }
+        const AGroup g = wq.slot[P & 3];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
             for (int c = 0; c < RC; ++c) {
-                acc0[c] = CEM_MFMA(g.a[r], hB[F][c][r], acc0[c]);
-                acc1[c] = CEM_MFMA(g.b[r], hB[F][c][r], acc1[c]);
+                acc0[c] = CEM_MFMA(g.a[r], hB[P][c][r], acc0[c]);
+                acc1[c] = CEM_MFMA(g.b[r], hB[P][c][r], acc1[c]);
             }
         }
-        CEM_FSTAMP(F);
-    }
-}
-
-template <int RC, int NB>
-__device__ __forceinline__ void cem_read_x(f4 (&hB)[CEM_NG][RC], const char *smem, const int xoff, const int lane)
-{
-#pragma unroll
-    for (int F = 0; F < NB; ++F) {
-#pragma unroll
-        for (int c = 0; c < RC; ++c)
-            hB[F][c] = *reinterpret_cast<const f4 *>(smem + xoff + ((c * CEM_NG + F) * 64 + lane) * 16);
     }
 }
 
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
     const int O = p.O, A = p.A, H = p.H;
     constexpr int XB = RC * CEM_NG * 1024;
     float *part = reinterpret_cast<float *>(smem + 2 * XB);
-    int xw = 0;                                          // buffer the next stage writes
+    int xw = 0;                                          // LDS buffer the current stage's outputs go to
     const PhiloxKey key = cem_key(p.ctrl);
 
     WRing wq;
@@ -281,14 +292,37 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
     bool done = false;
     const int nk = 1 + p.sc.n_cost;
 
+    // reward / cost / done bookkeeping of step T_ from the scorer terms in `part` (rows of the tile on wave 0's lanes);
+    // T_ = -1 only initialises d_prev / c_prev from s_0
+#define CEM_BOOKKEEP(T_) do { if (w == 0) { \
+        float dn = fminf(fminf(part[0 * 64 + lane], part[1 * 64 + lane]), fminf(part[2 * 64 + lane], part[3 * 64 + lane])); \
+        float cn = 0.f; \
+        for (int k = 1; k < nk; ++k) { \
+            const float dk = fminf(fminf(part[(k * 4 + 0) * 64 + lane], part[(k * 4 + 1) * 64 + lane]), \
+                                   fminf(part[(k * 4 + 2) * 64 + lane], part[(k * 4 + 3) * 64 + lane])); \
+            cn = cn + ((dk <= p.sc.cost_size[k - 1]) ? 1.0f : 0.0f); } \
+        if (p.sc.indicator) cn = cn > 0.f ? 1.0f : 0.0f; \
+        if ((T_) >= 0) { \
+            const bool ga = d_prev <= p.sc.goal_thresh;                                   /* safety_gym.py:116 */ \
+            float r = (d_prev - dn) * p.sc.reward_distance + (ga ? 1.0f : 0.0f) * p.sc.reward_goal; \
+            if (p.sc.reward_clip > 0.f) r = fminf(fmaxf(r, -p.sc.reward_clip), p.sc.reward_clip); \
+            if (p.variant == 1) {                                                         /* safe_cem_mpc.py:86-93 */ \
+                done = done || ga; \
+                const float nd = done ? 0.0f : 1.0f; \
+                const float cst = c_prev * nd; \
+                if (p.costs && lane < td.cnt) p.costs[(size_t)(T_) * p.Bloc + td.row_base + lane] = (uint8_t)cst; \
+                cum = cum + r * nd; \
+            } else {                                                                      /* mpc_policy.py:34-37 */ \
+                const float nd = done ? 0.0f : 1.0f; \
+                cum = cum + r * nd; \
+                done = done || ga; \
+            } } \
+        d_prev = dn; c_prev = cn; } } while (0)
+
     f4 hB[CEM_NG][RC];
 #ifdef CEM_STAMPS
     long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev_ = (long long)__builtin_amdgcn_s_memtime();
-    st_[7] = tprev_;                                     // absolute start (which dispatch round a tile ran in)
-#ifdef CEM_STAMPS_FINE
-    long long fst_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
 #endif
 
     for (int t = -1; t < H; ++t) {
@@ -301,8 +335,13 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
                 f4 acc0[RC], acc1[RC];
 #pragma unroll
                 for (int c = 0; c < RC; ++c) { acc0[c] = b0; acc1[c] = b1; }
-                if (l == 0) cem_mfma_stage<RC, 4 * NFW>(acc0, acc1, hB, wq);
-                else cem_mfma_stage<RC, CEM_NG>(acc0, acc1, hB, wq);
+                // stage input = previous stage's output buffer = xw ^ XB (the previous stage toggled xw after writing)
+                if (l == 0) {
+                    cem_mfma_stage<RC, 4 * NFW, NFW, true, true>(acc0, acc1, hB, wq, smem, xw ^ XB, lane, w);
+                    CEM_BOOKKEEP(t - 1);                  // the barrier inside the stage published step t-1's scorer terms
+                } else {
+                    cem_mfma_stage<RC, CEM_NG, 2, false, true>(acc0, acc1, hB, wq, smem, xw ^ XB, lane, w);
+                }
 #pragma unroll
                 for (int c = 0; c < RC; ++c) {
                     f4 h0 = acc0[c], h1 = acc1[c];
@@ -310,9 +349,8 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
                     for (int r = 0; r < 4; ++r) { h0[r] = fmaxf(h0[r], 0.f); h1[r] = fmaxf(h1[r], 0.f); }
                     *reinterpret_cast<f4 *>(smem + xw + ((c * CEM_NG + 2 * w) * 64 + lane) * 16) = h0;
                     *reinterpret_cast<f4 *>(smem + xw + ((c * CEM_NG + 2 * w + 1) * 64 + lane) * 16) = h1;
+                    hB[0][c] = h0; hB[1][c] = h1;         // own blocks of the next stage: no LDS round trip
                 }
-                __syncthreads();
-                cem_read_x<RC, CEM_NG>(hB, smem, xw, lane);
                 xw ^= XB;
                 CEM_STAMP(l == 0 ? 0 : 1);
             }
@@ -333,6 +371,7 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
         const float live = (t >= 0) ? 1.0f : 0.0f;          // prologue: no heads, the "update" adds exactly 0
         const float sampling = p.sampling ? 1.0f : 0.0f;
         const float goalm = p.sc.goal_mode ? 1.0f : 0.0f;
+        f4 xown[NFW][RC];
 
 #pragma unroll
         for (int i = 0; i < NFW; ++i) {
@@ -372,12 +411,15 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
 #pragma unroll
             for (int c = 0; c < RC; ++c) { accm[c] = bm; accv[c] = bv; }
             CEM_STAMP(2);
-#ifdef CEM_STAMPS_FINE
-            long long fprev_ = tprev_;
-            if (t >= 0 && Fo < p.KB_obs) cem_mfma_stage<RC, CEM_NG>(accm, accv, hB, wq, fst_, &fprev_);
-#else
-            if (t >= 0 && Fo < p.KB_obs) cem_mfma_stage<RC, CEM_NG>(accm, accv, hB, wq);      // wave-uniform
-#endif
+            if (t >= 0) {
+                // the first heads stage also performs the exchange of the last hidden layer's output
+                if (Fo < p.KB_obs) {                                                           // wave-uniform
+                    if (i == 0) cem_mfma_stage<RC, CEM_NG, 2, false, true>(accm, accv, hB, wq, smem, xw ^ XB, lane, w);
+                    else cem_mfma_stage<RC, CEM_NG, 2, false, false>(accm, accv, hB, wq, smem, xw ^ XB, lane, w);
+                } else if (i == 0) {
+                    __syncthreads();                      // keep the barrier count of waves without observation features
+                }
+            }
             CEM_STAMP(3);
 
 #pragma unroll
@@ -416,8 +458,14 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
                     }
                 }
                 *reinterpret_cast<f4 *>(smem + xw + ((c * CEM_NG + Fo) * 64 + lane) * 16) = x;
+                xown[i][c] = x;
             }
         }
+        // the wave's own input blocks of the next layer-0 stage stay in registers
+#pragma unroll
+        for (int i = 0; i < NFW; ++i)
+#pragma unroll
+            for (int c = 0; c < RC; ++c) hB[i][c] = xown[i][c];
         // cost kinds beyond the first (vases+hazards+pillars+gremlins all constrained): rare, kept out of the main block
         if (nk > 2) {
 #pragma unroll
@@ -451,52 +499,18 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
                 }
             }
         }
-        CEM_STAMP(4);
-        __syncthreads();
-        CEM_STAMP(5);
-
-        // ---- reward / cost / done bookkeeping of step t (rows of the tile on wave 0's lanes) ------------
-        if (w == 0) {
-            float dn = fminf(fminf(part[0 * 64 + lane], part[1 * 64 + lane]), fminf(part[2 * 64 + lane], part[3 * 64 + lane]));
-            float cn = 0.f;
-            for (int k = 1; k < nk; ++k) {
-                const float dk = fminf(fminf(part[(k * 4 + 0) * 64 + lane], part[(k * 4 + 1) * 64 + lane]),
-                                       fminf(part[(k * 4 + 2) * 64 + lane], part[(k * 4 + 3) * 64 + lane]));
-                cn = cn + ((dk <= p.sc.cost_size[k - 1]) ? 1.0f : 0.0f);
-            }
-            if (p.sc.indicator) cn = cn > 0.f ? 1.0f : 0.0f;
-            if (t >= 0) {
-                const bool ga = d_prev <= p.sc.goal_thresh;                                   // safety_gym.py:116
-                float r = (d_prev - dn) * p.sc.reward_distance + (ga ? 1.0f : 0.0f) * p.sc.reward_goal;
-                if (p.sc.reward_clip > 0.f) r = fminf(fmaxf(r, -p.sc.reward_clip), p.sc.reward_clip);
-                if (p.variant == 1) {                                                         // safe_cem_mpc.py:86-93
-                    done = done || ga;
-                    const float nd = done ? 0.0f : 1.0f;
-                    const float cst = c_prev * nd;
-                    if (p.costs && lane < td.cnt) p.costs[(size_t)t * p.Bloc + td.row_base + lane] = (uint8_t)cst;
-                    cum = cum + r * nd;
-                } else {                                                                      // mpc_policy.py:34-37
-                    const float nd = done ? 0.0f : 1.0f;
-                    cum = cum + r * nd;
-                    done = done || ga;
-                }
-            }
-            d_prev = dn;
-            c_prev = cn;
-        }
-        cem_read_x<RC, 4 * NFW>(hB, smem, xw, lane);
         xw ^= XB;
-        CEM_STAMP(6);
+        CEM_STAMP(4);
     }
+    // the last step's scorer terms: publish, then its bookkeeping
+    __syncthreads();
+    CEM_BOOKKEEP(H - 1);
     if (w == 0 && lane < td.cnt) p.ret[td.row_base + lane] = cum;
 #ifdef CEM_STAMPS
-#ifdef CEM_STAMPS_FINE
-    if (p.stamps && lane == 0) for (int i = 0; i < 8; ++i) p.stamps[((size_t)blockIdx.x * 4 + w) * 8 + i] = fst_[i];
-#else
     if (p.stamps && lane == 0) for (int i = 0; i < 8; ++i) p.stamps[((size_t)blockIdx.x * 4 + w) * 8 + i] = st_[i];
 #endif
-#endif
 }
+#undef CEM_BOOKKEEP
 
 // ---------------------------------------------------------------------------------------------------------
 // small kernels of the optimiser loop

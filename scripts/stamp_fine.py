@@ -12,6 +12,6 @@ for i in range(3):
     pl.plan(pb['state'], seed=1, call=i)
 rc, tiles = pl.tiles(); nt = len(tiles)
 st = pl._view(pl.layout.stamps, nt * 4 * 8, torch.int64).view(nt, 4, 8).cpu().numpy().astype(np.float64) / H
-print('heads chain, cycles per group F=0..7 (24 MFMA each = 768 ideal), waves 0..3, mean over tiles')
+print('hidden stages (x3 per step), cycles per group F=0..7 (24 MFMA each = 768 ideal), waves 0..3, mean over tiles')
 for w in range(4):
     print('wave %d:' % w, ' '.join('%6.0f' % st[:, w, F].mean() for F in range(8)), '  sum %.0f' % st[:, w, :].sum(axis=1).mean())

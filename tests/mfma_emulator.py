@@ -10,6 +10,18 @@ v_mfma_f32_16x16x4_f32 lane maps (cdna_hip_programming.md section 3):
 import numpy as np
 
 
+def perm_hidden(w, phi):
+    """csrc/cem_device.h cem_perm_hidden: the wave's own blocks 2w, 2w+1 first."""
+    return 2 * w + phi if phi < 2 else (phi - 2 if phi - 2 < 2 * w else phi)
+
+
+def perm_l0(w, nfw, phi):
+    """csrc/cem_device.h cem_perm_l0: the wave's own input blocks w, w+4, .. first."""
+    if phi < nfw:
+        return w + 4 * phi
+    return [F for F in range(4 * nfw) if (F & 3) != w][phi - nfw]
+
+
 def mfma_16x16x4(a, b, acc):
     """a[64], b[64] one float per lane; acc[64,4] -> acc + A.B in the D lane map."""
     A = a.reshape(4, 16).T.astype(np.float64)        # A[i][k]
@@ -41,13 +53,15 @@ class TileEmulator:
         self.pos[w] = (self.pos[w] + 1) % self.d['wave_groups'][w]
         return g
 
-    def stage(self, X, kf, rc):
-        """X[c][F][lane][r] (the LDS exchange image) -> per wave (acc0, acc1)[c][lane][4]."""
+    def stage(self, X, kf, rc, l0=False):
+        """X[c][F][lane][r] (the LDS exchange image) -> per wave (acc0, acc1)[c][lane][4].  Each wave visits the
+        k-blocks in its own order (own blocks first), which is also the order of its weight stream."""
         outs = []
         for w in range(4):
             acc0 = np.zeros((rc, 64, 4))
             acc1 = np.zeros((rc, 64, 4))
-            for F in range(kf):
+            for P in range(kf):
+                F = perm_l0(w, kf // 4, P) if l0 else perm_hidden(w, P)
                 g = self.pop(w)
                 for r in range(4):
                     for c in range(rc):
@@ -75,7 +89,7 @@ class TileEmulator:
                         X[c, F, lane, r] = x_rows[16 * c + j, f] if f < Din else 0.0
         hidden = []
         for l in range(d['L']):
-            outs = self.stage(X, d['KF0'] if l == 0 else 8, rc)
+            outs = self.stage(X, d['KF0'] if l == 0 else 8, rc, l0=(l == 0))
             Xn = np.zeros((rc, 8, 64, 4))
             for w in range(4):
                 for g in range(2):
@@ -104,7 +118,8 @@ class TileEmulator:
                 if Fo < d['KB_obs']:
                     acc_m = np.zeros((rc, 64, 4))
                     acc_v = np.zeros((rc, 64, 4))
-                    for F in range(8):
+                    for P in range(8):
+                        F = perm_hidden(w, P)
                         g = self.pop(w)
                         for r in range(4):
                             for c in range(rc):
