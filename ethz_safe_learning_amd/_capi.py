@@ -22,6 +22,8 @@ EXPORTED_SYMBOLS = [
     'cem_planner_create', 'cem_planner_destroy', 'cem_planner_layout', 'cem_planner_set_weights',
     'cem_planner_set_normaliser', 'cem_planner_plan', 'cem_plan_begin', 'cem_plan_rollout', 'cem_plan_select',
     'cem_plan_end', 'cem_unfold_sequences', 'cem_fill_noise', 'cem_planner_set_timing', 'cem_planner_last_timing',
+    'cem_trainer_workspace_bytes', 'cem_trainer_blob_floats', 'cem_trainer_create', 'cem_trainer_destroy', 'cem_trainer_set_state',
+    'cem_trainer_get_state', 'cem_trainer_step', 'cem_trainer_eval',
 ]
 
 
@@ -50,6 +52,12 @@ class CemConfig(C.Structure):
         ('scorer', CemScorer),
         ('world_size', C.c_int32), ('rank', C.c_int32), ('chunks_per_tile', C.c_int32), ('use_graph', C.c_int32),
     ]
+
+
+class CemTrainConfig(C.Structure):
+    _fields_ = [('abi_version', C.c_int32), ('inputs_dim', C.c_int32), ('outputs_dim', C.c_int32), ('units', C.c_int32),
+                ('n_layers', C.c_int32), ('ensemble_size', C.c_int32), ('batch_size', C.c_int32),
+                ('beta1', C.c_float), ('beta2', C.c_float), ('epsilon', C.c_float), ('clipvalue', C.c_float)]
 
 
 class CemLayout(C.Structure):
@@ -102,9 +110,20 @@ def load():
     lib.cem_fill_noise.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, vp]
     lib.cem_planner_set_timing.argtypes = [vp, C.c_int32]
     lib.cem_planner_last_timing.argtypes = [vp, fp, i32p, fp]
+    tcfgp = C.POINTER(CemTrainConfig)
+    for f in ('cem_trainer_workspace_bytes', 'cem_trainer_blob_floats'):
+        getattr(lib, f).restype = C.c_size_t
+        getattr(lib, f).argtypes = [tcfgp]
+    lib.cem_trainer_create.argtypes = [tcfgp, vp, C.c_size_t, vp, C.POINTER(vp)]
+    lib.cem_trainer_destroy.argtypes = [vp]
+    lib.cem_trainer_set_state.argtypes = [vp, vp, vp, vp]
+    lib.cem_trainer_get_state.argtypes = [vp, vp, vp, vp]
+    lib.cem_trainer_step.argtypes = [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_float, vp]
+    lib.cem_trainer_eval.argtypes = [vp, vp, vp, C.c_int32, fp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)          # raises AttributeError if the symbol is not exported
-        if name not in ('cem_status_string', 'cem_weight_blob_floats', 'cem_packed_weight_floats', 'cem_workspace_bytes'):
+        if name not in ('cem_status_string', 'cem_weight_blob_floats', 'cem_packed_weight_floats', 'cem_workspace_bytes',
+                        'cem_trainer_workspace_bytes', 'cem_trainer_blob_floats'):
             fn.restype = C.c_int
     if lib.cem_abi_version() != CEM_ABI_VERSION:
         raise ImportError('ABI mismatch: library %d, binding %d' % (lib.cem_abi_version(), CEM_ABI_VERSION))

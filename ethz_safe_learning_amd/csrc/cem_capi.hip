@@ -1,6 +1,7 @@
 // cem_capi.hip — host side of the C ABI declared in include/cem_mpc.h.
 // Built with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC (see csrc/build.sh).
 #include "cem_device.h"
+#include "cem_train.h"
 #include "../../include/cem_mpc.h"
 
 #include <algorithm>
@@ -717,6 +718,148 @@ int cem_planner_last_timing(cem_planner_t *h, float *rollout_ms_total, int32_t *
     if (rollout_ms_total) *rollout_ms_total = h->roll_ms;
     if (rollout_launches) *rollout_launches = h->roll_n;
     if (select_ms_total) *select_ms_total = h->sel_ms;
+    return CEM_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// training
+// ---------------------------------------------------------------------------------------------------------
+struct cem_trainer {
+    cem_train_config_t cfg;
+    char *ws; hipStream_t stream; bool own_stream;
+    size_t nat, scratch_pm;
+    size_t oW, oM, oV, oG, oS, oL, total;
+};
+
+namespace {
+int validate_train(const cem_train_config_t *c)
+{
+    if (!c || c->abi_version != CEM_ABI_VERSION) return CEM_ERR_INVALID_ARG;
+    if (c->inputs_dim < 1 || c->outputs_dim < 1 || c->n_layers < 1 || c->ensemble_size < 1 || c->batch_size < 1) return CEM_ERR_INVALID_ARG;
+    if (c->units != CEM_U || c->inputs_dim > CEM_U || c->outputs_dim > CEM_U || c->batch_size > CEM_TB) return CEM_ERR_UNSUPPORTED;
+    return CEM_OK;
+}
+size_t train_nat(const cem_train_config_t *c)
+{
+    return (size_t)c->inputs_dim * c->units + c->units + (size_t)(c->n_layers - 1) * ((size_t)c->units * c->units + c->units) +
+           2 * ((size_t)c->units * c->outputs_dim + c->outputs_dim);
+}
+void train_layout(cem_trainer *t)
+{
+    const cem_train_config_t &c = t->cfg;
+    t->nat = train_nat(&c);
+    t->scratch_pm = (size_t)(c.n_layers + 8) * CEM_TB * c.units;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
+    t->oW = take(t->nat * c.ensemble_size * 4); t->oM = take(t->nat * c.ensemble_size * 4); t->oV = take(t->nat * c.ensemble_size * 4);
+    t->oG = take(t->nat * c.ensemble_size * 4); t->oS = take(t->scratch_pm * c.ensemble_size * 4); t->oL = take((size_t)c.ensemble_size * 2 * 4);
+    t->total = o;
+}
+void fill_train_params(const cem_trainer *t, TrainParams &p)
+{
+    const cem_train_config_t &c = t->cfg;
+    std::memset(&p, 0, sizeof(p));
+    p.W = (float *)(t->ws + t->oW); p.Mo = (float *)(t->ws + t->oM); p.Vo = (float *)(t->ws + t->oV);
+    p.grad = (float *)(t->ws + t->oG); p.scratch = (float *)(t->ws + t->oS);
+    p.D = c.inputs_dim; p.O = c.outputs_dim; p.U = c.units; p.L = c.n_layers; p.E = c.ensemble_size;
+    p.nat = (uint32_t)t->nat; p.scratch_per_member = (uint32_t)t->scratch_pm;
+    p.beta1 = c.beta1; p.beta2 = c.beta2; p.eps = c.epsilon; p.clip = c.clipvalue;
+}
+}  // namespace
+
+extern "C" {
+
+size_t cem_trainer_workspace_bytes(const cem_train_config_t *cfg)
+{
+    if (validate_train(cfg)) return 0;
+    cem_trainer t; t.cfg = *cfg; train_layout(&t); return t.total;
+}
+size_t cem_trainer_blob_floats(const cem_train_config_t *cfg) { return validate_train(cfg) ? 0 : train_nat(cfg) * cfg->ensemble_size; }
+
+int cem_trainer_create(const cem_train_config_t *cfg, void *workspace, size_t workspace_bytes, void *hip_stream, cem_trainer_t **out)
+{
+    int st = validate_train(cfg); if (st) return st;
+    if (!workspace || !out) return CEM_ERR_INVALID_ARG;
+    cem_trainer *t = new (std::nothrow) cem_trainer();
+    if (!t) return CEM_ERR_INVALID_ARG;
+    t->cfg = *cfg; train_layout(t);
+    if (workspace_bytes < t->total || ((uintptr_t)workspace & 255)) { delete t; return CEM_ERR_WORKSPACE; }
+    t->ws = (char *)workspace; t->stream = (hipStream_t)hip_stream; t->own_stream = false;
+    if (!t->stream) {
+        if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) { g_last_hip = (int)hipGetLastError(); delete t; return CEM_ERR_HIP; }
+        t->own_stream = true;
+    }
+    if (hipMemsetAsync(t->ws, 0, t->total, t->stream) != hipSuccess || hipStreamSynchronize(t->stream) != hipSuccess) {
+        g_last_hip = (int)hipGetLastError(); delete t; return CEM_ERR_HIP;
+    }
+    *out = t;
+    return CEM_OK;
+}
+
+int cem_trainer_destroy(cem_trainer_t *t)
+{
+    if (!t) return CEM_ERR_INVALID_ARG;
+    if (t->own_stream) hipStreamDestroy(t->stream);
+    delete t;
+    return CEM_OK;
+}
+
+int cem_trainer_set_state(cem_trainer_t *t, const float *weights, const float *m, const float *v)
+{
+    if (!t || !weights) return CEM_ERR_INVALID_ARG;
+    const size_t bytes = t->nat * t->cfg.ensemble_size * 4;
+    HIPCHK(hipMemcpyAsync(t->ws + t->oW, weights, bytes, hipMemcpyHostToDevice, t->stream));
+    if (m) HIPCHK(hipMemcpyAsync(t->ws + t->oM, m, bytes, hipMemcpyHostToDevice, t->stream)); else HIPCHK(hipMemsetAsync(t->ws + t->oM, 0, bytes, t->stream));
+    if (v) HIPCHK(hipMemcpyAsync(t->ws + t->oV, v, bytes, hipMemcpyHostToDevice, t->stream)); else HIPCHK(hipMemsetAsync(t->ws + t->oV, 0, bytes, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    return CEM_OK;
+}
+
+int cem_trainer_get_state(cem_trainer_t *t, float *weights, float *m, float *v)
+{
+    if (!t) return CEM_ERR_INVALID_ARG;
+    const size_t bytes = t->nat * t->cfg.ensemble_size * 4;
+    if (weights) HIPCHK(hipMemcpyAsync(weights, t->ws + t->oW, bytes, hipMemcpyDeviceToHost, t->stream));
+    if (m) HIPCHK(hipMemcpyAsync(m, t->ws + t->oM, bytes, hipMemcpyDeviceToHost, t->stream));
+    if (v) HIPCHK(hipMemcpyAsync(v, t->ws + t->oV, bytes, hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    return CEM_OK;
+}
+
+int cem_trainer_step(cem_trainer_t *t, const float *x_dev, const float *y_dev, const int32_t *perm_dev, int32_t nperm, int32_t offset,
+                     int32_t bt, float lr_t, float *loss_dev)
+{
+    if (!t || !x_dev || !y_dev || !loss_dev || bt < 1 || bt > t->cfg.batch_size || offset < 0) return CEM_ERR_INVALID_ARG;
+    if (perm_dev && offset + bt > nperm) return CEM_ERR_INVALID_ARG;
+    TrainParams p; fill_train_params(t, p);
+    p.x = x_dev; p.y = y_dev; p.perm = perm_dev; p.nperm = nperm; p.offset = offset; p.Bt = bt; p.lr_t = lr_t; p.loss_out = loss_dev; p.train = 1;
+    hipLaunchKernelGGL(cem_train_step_kernel, dim3(t->cfg.ensemble_size), dim3(256), 0, t->stream, p);
+    HIPCHK(hipGetLastError());
+    return CEM_OK;
+}
+
+int cem_trainer_eval(cem_trainer_t *t, const float *x_dev, const float *y_dev, int32_t n, float *loss_out)
+{
+    if (!t || !x_dev || !y_dev || !loss_out || n < 1) return CEM_ERR_INVALID_ARG;
+    const int E = t->cfg.ensemble_size;
+    std::vector<float> sums((size_t)E * 2), part((size_t)E * 2);
+    std::fill(sums.begin(), sums.end(), 0.f);
+    TrainParams p; fill_train_params(t, p);
+    p.x = x_dev; p.y = y_dev; p.perm = nullptr; p.loss_out = (float *)(t->ws + t->oL); p.train = 0;
+    for (int off = 0; off < n; off += t->cfg.batch_size) {
+        p.offset = off; p.Bt = std::min(t->cfg.batch_size, n - off);
+        hipLaunchKernelGGL(cem_train_step_kernel, dim3(E), dim3(256), 0, t->stream, p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(part.data(), t->ws + t->oL, part.size() * 4, hipMemcpyDeviceToHost, t->stream));
+        HIPCHK(hipStreamSynchronize(t->stream));
+        for (size_t i = 0; i < sums.size(); ++i) sums[i] += part[i];
+    }
+    const double cnt = (double)n * t->cfg.outputs_dim;
+    double total = 0;
+    for (int m = 0; m < E; ++m) total += (0.5 * sums[2 * m] / cnt + 0.5 * sums[2 * m + 1] / cnt) / E;
+    *loss_out = (float)total;
     return CEM_OK;
 }
 

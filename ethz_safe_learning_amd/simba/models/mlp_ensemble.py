@@ -1,8 +1,14 @@
-"""MlpEnsemble (inference half), reference simba/models/mlp_ensemble.py:91-132,189-193: E independent Gaussian
-MLPs, L x (Dense U + ReLU) -> (mu Dense, softplus+1e-4 var Dense).  Holds the weights in Keras layout ([in, out],
-Glorot-uniform kernels, zero biases: Keras Dense defaults of mlp_ensemble.py:13,28-29); evaluation happens in the
-fused HIP kernel.  ``fit`` (mlp_ensemble.py:163-187) is SURVEY 8f row 1 ("next") and not implemented yet."""
+"""MlpEnsemble, reference simba/models/mlp_ensemble.py:91-193: E independent Gaussian MLPs, L x (Dense U + ReLU) ->
+(mu Dense, softplus+1e-4 var Dense).  Holds the weights in Keras layout ([in, out], Glorot-uniform kernels, zero
+biases: Keras Dense defaults of mlp_ensemble.py:13,28-29).  Inference happens in the fused HIP rollout kernel;
+``fit`` (mlp_ensemble.py:163-187) keeps the reference's host loop (train/validation split, per-epoch bootstrap
+shuffles, np.array_split batches, EpochLearningRateSchedule :70-88) and runs every training_step (:134-145) on the
+GPU through cem_trainer_step (forward, NLL, backward, Adam with clipvalue=1 / epsilon=1e-5)."""
+import logging
+
 import numpy as np
+
+logger = logging.getLogger('simba')
 
 
 class MlpEnsemble(object):
@@ -51,6 +57,67 @@ class MlpEnsemble(object):
         self._weights = weights
         self.version += 1
 
+    # ---- training (mlp_ensemble.py:70-88,134-187) ----------------------------------------------------------------
+    def learning_rate_at(self, step):
+        """EpochLearningRateSchedule.__call__ (:80-83) or the constant rate (:115)."""
+        f = np.float32
+        if not self.learning_rate_schedule:
+            return f(self.learning_rate)
+        epochs_so_far = f(np.floor(int(step) / int(self.training_steps)))
+        return max(f(self.learning_rate) * (f(1.0) - epochs_so_far / f(self.train_epochs)), f(0.0))
+
+    def split_train_validate(self, inputs, targets):
+        indices = np.random.permutation(inputs.shape[0])                                   # :157-161
+        num_val = int(inputs.shape[0] * self.validation_split)
+        train_idx, val_idx = indices[num_val:], indices[:num_val]
+        return inputs[train_idx, ...], targets[train_idx, ...], inputs[val_idx, ...], targets[val_idx, ...]
+
+    def _get_trainer(self, device='cuda:0'):
+        from ...trainer import CemTrainer
+        if getattr(self, '_trainer', None) is None:
+            self._trainer = CemTrainer(self.inputs_dim, self.outputs_dim, self.mlp_params['units'], self.mlp_params['n_layers'],
+                                       self.ensemble_size, batch_size=self.batch_size, device=device)
+            self._trainer_version = None
+        if self._trainer_version != self.version:           # weights were replaced from outside: Adam moments restart
+            self._trainer.set_state(self._weights)
+            self._trainer_version = self.version
+        return self._trainer
+
     def fit(self, inputs, targets):
-        raise NotImplementedError('MlpEnsemble.fit (mlp_ensemble.py:163-187) is the next hot-path row (SURVEY 8f-1); '
-                                  'load trained weights with set_weights()')
+        import torch
+        assert inputs.shape[0] == targets.shape[0], "Inputs batch size ({}) doesn't match targets batch size ({})".format(
+            inputs.shape[0], targets.shape[0])
+        assert np.isfinite(inputs).all() and np.isfinite(targets).all(), "Training data is not finite."      # :166
+        tr = self._get_trainer()
+        train_inputs, train_targets, validate_inputs, validate_targets = self.split_train_validate(
+            np.asarray(inputs, np.float32), np.asarray(targets, np.float32))
+        n_train = train_inputs.shape[0]
+        n_batches = int(np.ceil(n_train / self.batch_size))                                                   # :169
+        dev = tr.device
+        x_dev = torch.from_numpy(np.ascontiguousarray(train_inputs)).to(dev)
+        y_dev = torch.from_numpy(np.ascontiguousarray(train_targets)).to(dev)
+        xv_dev = torch.from_numpy(np.ascontiguousarray(validate_inputs)).to(dev) if validate_inputs.shape[0] else None
+        yv_dev = torch.from_numpy(np.ascontiguousarray(validate_targets)).to(dev) if validate_inputs.shape[0] else None
+        loss_dev = torch.zeros((self.training_steps, self.ensemble_size), dtype=torch.float32, device=dev)
+        bounds = np.cumsum([0] + [len(a) for a in np.array_split(np.arange(n_train), n_batches)])             # np.array_split sizes, :174
+        step = 0
+        log_every = max(1, int(self.training_steps / 10))
+        while step < self.training_steps:
+            shuffles_per_mlp = np.array([np.random.permutation(n_train) for _ in range(self.ensemble_size)])  # :172-173
+            perm_dev = torch.from_numpy(shuffles_per_mlp.astype(np.int32)).to(dev)
+            for b in range(n_batches):
+                off, bt = int(bounds[b]), int(bounds[b + 1] - bounds[b])
+                tr.step(x_dev, y_dev, perm_dev, off, bt, self.learning_rate_at(tr.iterations), loss_dev[step])
+                step += 1
+                if step % log_every == 0 and xv_dev is not None:                                              # :181-184
+                    vl = tr.validation_loss(xv_dev, yv_dev)
+                    logger.debug("Step {} | Training Loss {} | Validation Loss {}".format(
+                        step, float(loss_dev[step - 1].sum().item()), vl))
+                if step == self.training_steps:
+                    break
+        tr.synchronize()
+        losses = loss_dev.sum(dim=1).cpu().numpy().astype(np.float64)
+        self._weights = tr.get_weights()
+        self.version += 1
+        self._trainer_version = self.version
+        return losses

@@ -167,6 +167,35 @@ int cem_fill_noise(cem_planner_t *h, uint64_t seed, uint64_t call, float *eps_ac
 int cem_planner_set_timing(cem_planner_t *h, int32_t enable);
 int cem_planner_last_timing(cem_planner_t *h, float *rollout_ms_total, int32_t *rollout_launches, float *select_ms_total);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Ensemble training on the device: MlpEnsemble.training_step / validation_step
+ * (simba/models/mlp_ensemble.py:134-155), loss negative_log_likelihood (:64-67), optimizer
+ * tf.keras.optimizers.Adam(lr, clipvalue=1.0, epsilon=1e-5) (:113-117).  The shuffling / batching / learning-rate
+ * schedule loop of fit() (:163-187, :70-88) is host logic above this ABI.  Weights use the natural blob layout above,
+ * so the result of training feeds cem_planner_set_weights() unchanged. */
+typedef struct cem_train_config {
+    int32_t abi_version;
+    int32_t inputs_dim, outputs_dim, units, n_layers, ensemble_size;
+    int32_t batch_size;           /* rows per member per step, <= 64 (config/models.yaml:4) */
+    float beta1, beta2, epsilon, clipvalue;
+} cem_train_config_t;
+typedef struct cem_trainer cem_trainer_t;
+
+size_t cem_trainer_workspace_bytes(const cem_train_config_t *cfg);
+size_t cem_trainer_blob_floats(const cem_train_config_t *cfg);
+int cem_trainer_create(const cem_train_config_t *cfg, void *workspace, size_t workspace_bytes, void *hip_stream, cem_trainer_t **out);
+int cem_trainer_destroy(cem_trainer_t *h);
+/* weights + Adam moments (host blobs; moments may be NULL = zeros) */
+int cem_trainer_set_state(cem_trainer_t *h, const float *weights, const float *m, const float *v);
+int cem_trainer_get_state(cem_trainer_t *h, float *weights, float *m, float *v);
+/* one training_step on rows perm[member][offset .. offset+bt) of x_dev[n][inputs_dim] / y_dev[n][outputs_dim];
+ * lr_t = lr * sqrt(1-beta2^t)/(1-beta1^t) (Keras folds the bias correction into the step size);
+ * loss_dev[ensemble_size] receives every member's share of the loss (their sum is training_step's return value) */
+int cem_trainer_step(cem_trainer_t *h, const float *x_dev, const float *y_dev, const int32_t *perm_dev, int32_t nperm,
+                     int32_t offset, int32_t bt, float lr_t, float *loss_dev);
+/* validation_step on rows [0, n) of x_dev / y_dev: *loss_out = sum over members of NLL / ensemble_size (synchronises) */
+int cem_trainer_eval(cem_trainer_t *h, const float *x_dev, const float *y_dev, int32_t n, float *loss_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,94 @@
+"""Parity of the device training step (cem_trainer_*) against the oracle's manual-backward restatement of
+MlpEnsemble.training_step / validation_step, and MlpEnsemble.fit end to end.
+Tolerances: fp32 forward/backward with different summation orders: losses within 1e-5 rel, weights after a few Adam steps
+within 2e-5 abs (Adam's first steps move every weight by ~lr regardless of gradient size, so tiny gradients amplify
+rounding into the sign of the update only where |g| ~ 1e-12: none here)."""
+import numpy as np
+import pytest
+
+from oracle import cem_oracle as o
+from tests import helpers as hp
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(E=3, D=62, O=60, L=4, seed=0):
+    pb = hp.make_problem(O, D - O, E, L, seed=seed, bias_noise=0.05, head_scale=0.3, var_bias=-2.0)
+    rng = np.random.default_rng(seed)
+    n = 500
+    X = rng.normal(0, 0.5, (n, D)).astype(np.float32)
+    Y = (0.1 * X[:, :O] + 0.05 * rng.normal(0, 1, (n, O))).astype(np.float32)
+    return pb, X, Y, rng
+
+
+@pytest.mark.parametrize('E,D,O,L,bt', [(3, 62, 60, 4, 64), (2, 8, 6, 2, 37), (2, 112, 100, 3, 64)])
+def test_training_steps_match_oracle(E, D, O, L, bt):
+    import torch
+    from ethz_safe_learning_amd.trainer import CemTrainer
+    pb, X, Y, rng = _setup(E, D, O, L, seed=E)
+    tr = CemTrainer(D, O, 128, L, E, batch_size=64)
+    tr.set_state(pb['weights'])
+    w = o.cast_weights(pb['weights'], np.float32)
+    ms, vs = o.zeros_like_weights(w), o.zeros_like_weights(w)
+    w64 = o.cast_weights(pb['weights'], np.float64)
+    ms64, vs64 = o.zeros_like_weights(w64), o.zeros_like_weights(w64)
+    x_dev, y_dev = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()
+    lr = 0.00025
+    for t in range(1, 5):
+        perm = np.stack([rng.permutation(X.shape[0]) for _ in range(E)]).astype(np.int32)
+        perm_dev = torch.from_numpy(perm).cuda()
+        loss_dev = torch.zeros(E, device='cuda')
+        off = 7 * t
+        tr.step(x_dev, y_dev, perm_dev, off, bt, lr, loss_dev)
+        tr.synchronize()
+        idx = perm[:, off:off + bt]
+        ref = o.training_step(w64, ms64, vs64, X[idx].astype(np.float64), Y[idx].astype(np.float64), lr, t)
+        ref32 = o.training_step(w, ms, vs, X[idx], Y[idx], np.float32(lr), t)
+        got = float(loss_dev.sum().item())
+        assert abs(got - ref) <= 1e-5 * max(1.0, abs(ref)), (t, got, ref, ref32)
+    gw = tr.get_weights()
+    worst = 0.0
+    for a, b in zip(gw, w64):
+        for ka, kb in zip(o._flat_params(a), o._flat_params(b)):
+            worst = max(worst, float(np.abs(ka - kb).max()))
+    print('max |w_gpu - w_f64| after 4 Adam steps: %.3g (lr %.3g)' % (worst, lr))
+    assert worst <= 2e-5
+    gm, gv = tr.get_moments()
+    for a, b in zip(gm, ms64):
+        for ka, kb in zip(o._flat_params(a), o._flat_params(b)):
+            np.testing.assert_allclose(ka, kb, rtol=2e-3, atol=1e-7)
+    # validation_step on a held-out slice
+    vl = tr.validation_loss(x_dev[:130], y_dev[:130])
+    ref_vl = o.validation_loss(o.cast_weights(gw, np.float64), X[:130].astype(np.float64), Y[:130].astype(np.float64))
+    assert abs(vl - ref_vl) <= 1e-5 * max(1.0, abs(ref_vl))
+
+
+def test_fit_learns_and_feeds_the_planner():
+    """TransitionModel.fit -> MlpEnsemble.fit (reference loop) on a learnable synthetic transition function, then the
+    planner picks the new weights up through model.version."""
+    from tests.test_simba_api import make_agent_parts
+    np.random.seed(0)
+    env, model, pol = make_agent_parts('cem_mpc', seed=1)
+    model.model.training_steps = 300
+    model.model.train_epochs = 10
+    rng = np.random.default_rng(0)
+    n = 2000
+    obs = np.zeros((n, 60), np.float32)
+    obs[:] = rng.normal(0, 0.3, (n, 60))
+    for lo, hi in ((3, 19), (22, 38), (41, 57)):
+        obs[:, lo:hi] = rng.uniform(0.1, 0.9, (n, hi - lo))
+    act = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+    A = rng.normal(0, 0.02, (62, 60)).astype(np.float32)
+    nxt = obs + np.concatenate([obs, act], 1) @ A + 0.002 * rng.normal(0, 1, (n, 60)).astype(np.float32)
+    v0 = model.version
+    losses = model.fit(np.concatenate([obs, act], 1), nxt)
+    assert losses.shape == (300,) and np.isfinite(losses).all()
+    assert losses[-20:].mean() < losses[:20].mean() - 0.5, (losses[:20].mean(), losses[-20:].mean())
+    assert model.version != v0
+    a = pol.generate_action(obs[0])
+    assert a.shape == (2,) and np.all(np.isfinite(a))
+    # Adam state and the iteration counter persist across fit() calls (one Keras optimizer per MlpEnsemble)
+    it0 = model.model._trainer.iterations
+    model.fit(np.concatenate([obs, act], 1), nxt)
+    assert model.model._trainer.iterations == it0 + 300
+    assert model.model.learning_rate_at(300) < model.model.learning_rate_at(0)
