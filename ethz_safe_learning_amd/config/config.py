@@ -1,0 +1,59 @@
+"""Experiment configuration: built-in defaults for policies / models / agents (the hyper-parameters the reference ships
+in config/policies.yaml, config/models.yaml, config/agents.yaml) overridden recursively by an experiment YAML
+(reference config/config.py:5-39).  ``load_config_or_die(config_dir, config_basename)`` keeps the reference's signature;
+if the directory also holds models.yaml / policies.yaml / agents.yaml they replace the built-in defaults."""
+import copy
+import os
+
+import yaml
+
+DEFAULTS = {
+    'policies': {
+        'cem_mpc': dict(horizon=8, iterations=10, smoothing=0.0, n_samples=150, n_elite=15, particles=5, stddev_threshold=0.25,
+                        noise_stddev=0.001),
+        'safe_cem_mpc': dict(horizon=8, iterations=9, smoothing=0.0, n_samples=500, n_elite=20, particles=45, stddev_threshold=0.25,
+                             noise_stddev=0.01, posterior_mean_threashold=0.15),
+    },
+    'models': {
+        'mlp_ensemble': dict(ensemble_size=15, batch_size=64, validation_split=0.2, learning_rate=0.00025, learning_rate_schedule=True,
+                             training_steps=5000, mlp_params=dict(n_layers=4, units=128, activation='tf.nn.relu', dropout_rate=0.0)),
+    },
+    'agents': {
+        'agent': dict(replay_buffer_size=1000000, action_repeat=6, add_observation_noise=False),
+        'mbrl_agent': dict(train_batch_size=30000, train_interaction_steps=1000, episode_length=1000, warmup_timesteps=5000,
+                           policy='safe_cem_mpc', model='mlp_ensemble', scale_features=True, sampling_propagation=True),
+    },
+}
+
+
+def overwrite_default_values(update_from, update_to):
+    for key, value in update_from.items():
+        if isinstance(value, dict) and isinstance(update_to.get(key), dict):
+            overwrite_default_values(value, update_to[key])
+        else:
+            update_to[key] = value
+    return update_to
+
+
+def load_config_or_die(config_dir, config_basename):
+    config = copy.deepcopy(DEFAULTS)
+    for filename in ('models.yaml', 'policies.yaml', 'agents.yaml'):
+        path = os.path.join(config_dir, filename)
+        if os.path.exists(path):
+            with open(path, 'r') as fh:
+                config.update(yaml.safe_load(fh))
+    with open(os.path.join(config_dir, config_basename), 'r') as fh:
+        overwrite_default_values(yaml.safe_load(fh) or {}, config)
+    return config
+
+
+def pretty_print(config, indent=0):
+    lines = []
+    for key, value in config.items():
+        head = '  ' * indent + str(key).ljust(30 - 2 * indent)
+        if isinstance(value, dict):
+            lines.append(head)
+            lines.append(pretty_print(value, indent + 1).rstrip('\n'))
+        else:
+            lines.append(head + str(value))
+    return '\n'.join(lines) + '\n'
