@@ -361,3 +361,42 @@ def pack_weights_host(cfg: PlannerConfig, weights) -> np.ndarray:
     out = np.zeros(lib.cem_packed_weight_floats(C.byref(cc)), np.float32)
     _capi.check(lib.cem_pack_weights_host(C.byref(cc), _np_ptr(blob), _np_ptr(out)), 'cem_pack_weights_host')
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Shape-keyed handle cache: scripts/tune_cem_policy.py replaces agent.policy with fresh CemMpc objects
+# of different (H, I, N, k) at run time (reference scripts/tune_cem_policy.py:109-115, "to trigger tensorflow's
+# retracing").  A planner handle is this build's "traced graph": one per distinct shape, reused when a shape recurs.
+# ---------------------------------------------------------------------------------------------------------------
+_PLANNER_CACHE = {}
+_PLANNER_CACHE_MAX = 32
+
+
+def _freeze(v):
+    if isinstance(v, np.ndarray):
+        return tuple(np.asarray(v, np.float64).ravel().tolist())
+    if isinstance(v, (list, tuple)):
+        return tuple(_freeze(x) for x in v)
+    if hasattr(v, '__dataclass_fields__'):
+        return tuple((k, _freeze(getattr(v, k))) for k in v.__dataclass_fields__)
+    return v
+
+
+def config_key(cfg: PlannerConfig, device='cuda:0'):
+    return (str(device),) + _freeze(cfg)
+
+
+def cached_planner(cfg: PlannerConfig, device='cuda:0') -> CemPlanner:
+    key = config_key(cfg, device)
+    pl = _PLANNER_CACHE.pop(key, None)
+    if pl is None:
+        pl = CemPlanner(cfg, device=device)
+        pl.staged = None                         # (id(model), model.version) whose weights/normaliser are on the device
+        while len(_PLANNER_CACHE) >= _PLANNER_CACHE_MAX:
+            _PLANNER_CACHE.pop(next(iter(_PLANNER_CACHE))).close()
+    _PLANNER_CACHE[key] = pl                     # most recently used last
+    return pl
+
+
+def planner_cache_info():
+    return dict(size=len(_PLANNER_CACHE), keys=list(_PLANNER_CACHE.keys()))

@@ -7,7 +7,7 @@ policy object, as in scripts/tune_cem_policy.py:109-115).  Weights / normaliser 
 ``version`` changed (after ``fit``: mbrl_agent.py:53)."""
 import numpy as np
 
-from ...planner import CemPlanner, PlannerConfig
+from ...planner import PlannerConfig, cached_planner
 from .mpc_policy import MpcPolicy
 
 
@@ -55,14 +55,16 @@ class CemMpc(MpcPolicy):
 
     def build(self):
         if self._planner is None:
-            self._planner = CemPlanner(self.planner_config(), device=self.device)
+            # one handle per distinct shape, shared by every policy object of that shape (tune_cem_policy.py:109-115)
+            self._planner = cached_planner(self.planner_config(), device=self.device)
         self._sync_model()
 
     def _sync_model(self):
-        if self._model_version != self.model.version:
+        tag = (id(self.model), self.model.version)
+        if self._planner.staged != tag:
             self._planner.set_weights(self.model.model.get_weights())
             self._planner.set_normaliser(self.model.inputs_min, self.model.inputs_max)
-            self._model_version = self.model.version
+            self._planner.staged = tag
 
     # ---- the plugin boundary ------------------------------------------------------------------------------------
     def generate_action(self, state):

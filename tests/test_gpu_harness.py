@@ -27,3 +27,27 @@ def test_train_script_smoke(tmp_path):
     tags = {r['tag'] for r in recs}
     assert {'eval_rl_objective', 'sum_rewards_stddev', 'eval_mean_sum_costs', 'sum_costs', 'training_rl_objective', 'mean_sum_costs'} <= tags
     assert all(np.isfinite(r['value']) for r in recs)
+
+
+def test_tune_cem_policy_grid_reuses_handles(tmp_path):
+    """SURVEY 8f-3: the CEM grid-tuning harness swaps agent.policy for fresh CemMpc objects of different (H, I, N, k);
+    every distinct shape gets one cached planner handle, recurring shapes reuse it."""
+    sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+    import tune_cem_policy as tune
+    from ethz_safe_learning_amd import planner
+    before = planner.planner_cache_info()['size']
+    res = tune.main(['--config_dir', os.path.join(ROOT, 'ethz_safe_learning_amd', 'config'), '--config_basename', 'smoke.yaml',
+                     '--log_dir', str(tmp_path), '--name', 'tune', '--seed', '1', '--log_level', 'WARNING', '--eval_steps', '120',
+                     '--eval_episode_length', '120', '--quick'])
+    assert len(res) == 8 and all(np.isfinite(r['score_mean']) and np.isfinite(r['cost_mean']) for r in res)
+    assert {(r['horizon'], r['n_samples'], r['iterations']) for r in res} == {(8, 150, 10), (8, 300, 5), (10, 150, 10), (10, 300, 5)}
+    assert [r['n_elite'] for r in res[:2]] == [round(0.05 * 150), 15]
+    grown = planner.planner_cache_info()['size'] - before
+    assert 8 <= grown <= 9                                     # 8 distinct CemMpc shapes (+ the training run's safe policy)
+    res2 = tune.grid_search.__wrapped__ if hasattr(tune.grid_search, '__wrapped__') else None
+    # the same shape again -> no new handle
+    from ethz_safe_learning_amd.simba.policies import CemMpc
+    n0 = planner.planner_cache_info()['size']
+    import glob
+    assert glob.glob(os.path.join(str(tmp_path), 'tune_*', 'training_data', 'grid_search.json'))
+    assert planner.planner_cache_info()['size'] == n0
