@@ -836,6 +836,9 @@ int cem_trainer_step(cem_trainer_t *t, const float *x_dev, const float *y_dev, c
     TrainParams p; fill_train_params(t, p);
     p.x = x_dev; p.y = y_dev; p.perm = perm_dev; p.nperm = nperm; p.offset = offset; p.Bt = bt; p.lr_t = lr_t; p.loss_out = loss_dev; p.train = 1;
     hipLaunchKernelGGL(cem_train_step_kernel, dim3(t->cfg.ensemble_size), dim3(256), 0, t->stream, p);
+    const size_t n4 = (size_t)p.E * p.nat / 4;
+    const unsigned adam_grid = (unsigned)std::min<size_t>(std::max<size_t>((n4 + 255) / 256, 1), 2048);
+    hipLaunchKernelGGL(cem_adam_kernel, dim3(adam_grid), dim3(256), 0, t->stream, p);
     HIPCHK(hipGetLastError());
     return CEM_OK;
 }

@@ -183,13 +183,14 @@ __host__ __device__ inline int cem_perm_l0(int w, int nfw, int phi)      // laye
 // MFMAs.  Every stage consumes a multiple of 4 groups (layer 0 is zero-padded to 4*NFW groups on the host), so the
 // slot of stage-local group phi is the compile-time constant phi & 3: no register moves, no branches.
 struct WRing {
-    const f4 *base;
+    const f4 *base;          // wave-uniform stream base: the per-lane part is a constant offset, so the loads take the
+    int lane;                // scalar-base form and no VALU address arithmetic sits in the MFMA stream
     int n, pos;
     AGroup slot[4];
-    __device__ __forceinline__ AGroup ld(int g) const { AGroup r; r.a = base[g * 128]; r.b = base[g * 128 + 64]; return r; }
-    __device__ __forceinline__ void init(const f4 *b, int n_)
+    __device__ __forceinline__ AGroup ld(int g) const { AGroup r; r.a = base[g * 128 + lane]; r.b = base[g * 128 + 64 + lane]; return r; }
+    __device__ __forceinline__ void init(const f4 *b, int lane_, int n_)
     {
-        base = b; n = n_;
+        base = b; lane = lane_; n = n_;
         slot[0] = ld(0); slot[1] = ld(1 % n_); slot[2] = ld(2 % n_); slot[3] = slot[2];
         pos = 3 % n_;
     }
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
     const PhiloxKey key = cem_key(p.ctrl);
 
     WRing wq;
-    wq.init(p.wpack + (size_t)td.member * p.member_stride_f4 + p.wave_off_f4[w] + lane, (int)p.wave_groups[w]);
+    wq.init(p.wpack + (size_t)td.member * p.member_stride_f4 + p.wave_off_f4[w], lane, (int)p.wave_groups[w]);
 
     const float *bias_h = p.bias_h + (size_t)td.member * p.L * CEM_U;
     const float *bias_mu = p.bias_mu + (size_t)td.member * CEM_U;
@@ -286,6 +287,11 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
             }
         }
     }
+
+    // per-chunk action-sequence row of this lane's batch row (64-bit address arithmetic once, not every step)
+    const float *actrow[RC];
+#pragma unroll
+    for (int c = 0; c < RC; ++c) actrow[c] = p.actions + (size_t)(td.act_base + slotc[c]) * H * A;
 
     // score owner (wave 0, lane == row slot)
     float d_prev = 0.f, c_prev = 0.f, cum = 0.f;
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     int af = f0 + r - O; af = af < 0 ? 0 : (af >= A ? A - 1 : af);
-                    act4[c][r] = p.actions[((size_t)(td.act_base + slotc[c]) * H + tn) * A + af];
+                    act4[c][r] = actrow[c][tn * A + af];
                 }
                 if (MODE == 1 && p.eps_model) {
                     const int tc = t < 0 ? 0 : t;

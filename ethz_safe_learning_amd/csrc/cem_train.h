@@ -26,14 +26,22 @@ struct TrainParams {
     int32_t train;
 };
 
-// C(m,n) = sum_k A(m,k) B(k,n) with A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]; epi(m, n, value)
+// C(m,n) = sum_k A(m,k) B(k,n) with A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]; epi(m, n, value).
+// 64x64 output tile per pass, k in slabs of CEM_TK staged through a double-buffered LDS tile; the next slab's global
+// loads are issued into registers before the current slab's FMAs, so the L2 latency hides behind the arithmetic and a
+// slab costs one barrier.
+#define CEM_TK 32
+#define CEM_TRAIN_LDS_FLOATS (2 * 2 * CEM_TK * 68)
 template <class Epi>
 __device__ __forceinline__ void wg_gemm(const int M, const int N, const int K, const float *A, const int sam, const int sak,
                                         const float *B, const int sbk, const int sbn, Epi epi, float *lds)
 {
-    float (*As)[68] = reinterpret_cast<float (*)[68]>(lds);
-    float (*Bs)[68] = reinterpret_cast<float (*)[68]>(lds + 16 * 68);
+    typedef float Tile[CEM_TK][68];
+    Tile *As = reinterpret_cast<Tile *>(lds);                       // As[buf][k][m]
+    Tile *Bs = reinterpret_cast<Tile *>(lds + 2 * CEM_TK * 68);     // Bs[buf][k][n]
+    constexpr int NE = 64 * CEM_TK / 256;                           // elements per thread per operand slab
     const int tid = threadIdx.x, tm = tid >> 4, tn = tid & 15;
+    const int nk = (K + CEM_TK - 1) / CEM_TK;
     for (int m0 = 0; m0 < M; m0 += 64) {
         for (int n0 = 0; n0 < N; n0 += 64) {
             float acc[4][4];
@@ -41,30 +49,50 @@ __device__ __forceinline__ void wg_gemm(const int M, const int N, const int K, c
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int jn = 0; jn < 4; ++jn) acc[i][jn] = 0.f;
-            for (int k0 = 0; k0 < K; k0 += 16) {
+            float ra[NE], rb[NE];
+            auto fetch = [&](const int k0) {
 #pragma unroll
-                for (int e4 = 0; e4 < 4; ++e4) {
-                    const int e = tid + 256 * e4;
+                for (int q = 0; q < NE; ++q) {
+                    const int e = tid + 256 * q;
                     int mm, kk;
-                    if (sak == 1) { kk = e & 15; mm = e >> 4; } else { mm = e & 63; kk = e >> 6; }      // coalesce along the unit stride
+                    if (sak == 1) { kk = e % CEM_TK; mm = e / CEM_TK; } else { mm = e & 63; kk = e >> 6; }      // coalesce along the unit stride
                     const int gm = m0 + mm, gk = k0 + kk;
-                    As[kk][mm] = (gm < M && gk < K) ? A[(size_t)gm * sam + (size_t)gk * sak] : 0.f;
+                    ra[q] = (gm < M && gk < K) ? A[(size_t)gm * sam + (size_t)gk * sak] : 0.f;
                     int nn, kb;
-                    if (sbn == 1) { nn = e & 63; kb = e >> 6; } else { kb = e & 15; nn = e >> 4; }
+                    if (sbn == 1) { nn = e & 63; kb = e >> 6; } else { kb = e % CEM_TK; nn = e / CEM_TK; }
                     const int gn = n0 + nn, gkb = k0 + kb;
-                    Bs[kb][nn] = (gn < N && gkb < K) ? B[(size_t)gkb * sbk + (size_t)gn * sbn] : 0.f;
+                    rb[q] = (gn < N && gkb < K) ? B[(size_t)gkb * sbk + (size_t)gn * sbn] : 0.f;
                 }
-                __syncthreads();
+            };
+            auto stash = [&](const int buf) {
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk) {
-                    const float4 a = *reinterpret_cast<const float4 *>(&As[kk][tm * 4]);
-                    const float4 b = *reinterpret_cast<const float4 *>(&Bs[kk][tn * 4]);
+                for (int q = 0; q < NE; ++q) {
+                    const int e = tid + 256 * q;
+                    int mm, kk;
+                    if (sak == 1) { kk = e % CEM_TK; mm = e / CEM_TK; } else { mm = e & 63; kk = e >> 6; }
+                    As[buf][kk][mm] = ra[q];
+                    int nn, kb;
+                    if (sbn == 1) { nn = e & 63; kb = e >> 6; } else { kb = e % CEM_TK; nn = e / CEM_TK; }
+                    Bs[buf][kb][nn] = rb[q];
+                }
+            };
+            fetch(0);
+            stash(0);
+            __syncthreads();
+            for (int kt = 0; kt < nk; ++kt) {
+                const int buf = kt & 1;
+                if (kt + 1 < nk) fetch((kt + 1) * CEM_TK);
+#pragma unroll
+                for (int kk = 0; kk < CEM_TK; ++kk) {
+                    const float4 a = *reinterpret_cast<const float4 *>(&As[buf][kk][tm * 4]);
+                    const float4 b = *reinterpret_cast<const float4 *>(&Bs[buf][kk][tn * 4]);
                     const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int jn = 0; jn < 4; ++jn) acc[i][jn] = __builtin_fmaf(av[i], bv[jn], acc[i][jn]);
                 }
+                if (kt + 1 < nk) stash(buf ^ 1);
                 __syncthreads();
             }
 #pragma unroll
@@ -88,6 +116,21 @@ __device__ __forceinline__ float train_softplus(float x)         // Eigen's thre
     return log1pf(ex);
 }
 
+// Elementwise pass over n items with the loads of CEM_UNR items in flight at once: one wave per SIMD has nobody to hide a
+// load behind, so a plain `for (e = tid; ...)` loop pays the whole L2 latency every iteration.
+#define CEM_UNR 8
+template <class T, class Ld, class St>
+__device__ __forceinline__ void wg_map(const int n, Ld ld, St st)
+{
+    for (int base = 0; base < n; base += 256 * CEM_UNR) {
+        T v[CEM_UNR];
+#pragma unroll
+        for (int q = 0; q < CEM_UNR; ++q) { const int e = base + q * 256 + (int)threadIdx.x; if (e < n) v[q] = ld(e); }
+#pragma unroll
+        for (int q = 0; q < CEM_UNR; ++q) { const int e = base + q * 256 + (int)threadIdx.x; if (e < n) st(e, v[q]); }
+    }
+}
+
 __device__ __forceinline__ float block_sum(float v, float *red)
 {
     const int tid = threadIdx.x;
@@ -103,7 +146,7 @@ __device__ __forceinline__ float block_sum(float v, float *red)
 
 __global__ __launch_bounds__(256) void cem_train_step_kernel(const TrainParams p)
 {
-    __shared__ __attribute__((aligned(16))) float lds[2 * 16 * 68];
+    __shared__ __attribute__((aligned(16))) float lds[CEM_TRAIN_LDS_FLOATS];
     __shared__ float red[4];
     const int m = blockIdx.x, tid = threadIdx.x;
     const int D = p.D, O = p.O, U = p.U, L = p.L, Bt = p.Bt;
@@ -126,11 +169,14 @@ __global__ __launch_bounds__(256) void cem_train_step_kernel(const TrainParams p
     const size_t oWv = obmu + O, obv = oWv + (size_t)U * O;
 
     // ---- gather the minibatch ---------------------------------------------------------------------------------
-    for (int e = tid; e < Bt * U; e += 256) {
-        const int r = e / U, c = e % U;
-        const int row = p.perm ? p.perm[(size_t)m * p.nperm + p.offset + r] : p.offset + r;
-        xs[e] = c < D ? p.x[(size_t)row * D + c] : 0.f;
-        ys[e] = c < O ? p.y[(size_t)row * O + c] : 0.f;
+    {
+        int32_t *rows = reinterpret_cast<int32_t *>(lds);
+        if (tid < Bt) rows[tid] = p.perm ? p.perm[(size_t)m * p.nperm + p.offset + tid] : p.offset + tid;
+        __syncthreads();
+        wg_map<float2>(Bt * U,
+            [&](int e) { const int r = e / U, c = e % U; const int row = rows[r];
+                         return make_float2(c < D ? p.x[(size_t)row * D + c] : 0.f, c < O ? p.y[(size_t)row * O + c] : 0.f); },
+            [&](int e, float2 v) { xs[e] = v.x; ys[e] = v.y; });
     }
     __syncthreads();
 
@@ -148,18 +194,20 @@ __global__ __launch_bounds__(256) void cem_train_step_kernel(const TrainParams p
     // ---- negative_log_likelihood (:64-67) and its gradient w.r.t. mu and the pre-softplus variance -----------------
     float s_log = 0.f, s_sq = 0.f;
     const float ninv = 1.0f / ((float)Bt * (float)O * (float)p.E);
-    for (int e = tid; e < Bt * O; e += 256) {
-        const int r = e / O, c = e % O;
-        const float v = vp[r * U + c], var = train_softplus(v) + 1e-4f;
-        const float diff = mu[r * U + c] - ys[r * U + c];
-        s_log += logf(6.283185307179586f * var);
-        s_sq += diff * diff / var;
-        if (p.train) {
-            dmu[r * U + c] = diff / var * ninv;
-            const float dvar = (0.5f / var - 0.5f * diff * diff / (var * var)) * ninv;
-            dv[r * U + c] = dvar / (1.0f + expf(-v));               // d softplus(v)/dv = sigmoid(v)
-        }
-    }
+    wg_map<float3>(Bt * O,
+        [&](int e) { const int r = e / O, c = e % O; return make_float3(vp[r * U + c], mu[r * U + c], ys[r * U + c]); },
+        [&](int e, float3 in) {
+            const int r = e / O, c = e % O;
+            const float v = in.x, var = train_softplus(v) + 1e-4f;
+            const float diff = in.y - in.z;
+            s_log += logf(6.283185307179586f * var);
+            s_sq += diff * diff / var;
+            if (p.train) {
+                dmu[r * U + c] = diff / var * ninv;
+                const float dvar = (0.5f / var - 0.5f * diff * diff / (var * var)) * ninv;
+                dv[r * U + c] = dvar / (1.0f + expf(-v));               // d softplus(v)/dv = sigmoid(v)
+            }
+        });
     s_log = block_sum(s_log, red);
     s_sq = block_sum(s_sq, red);
     if (!p.train) {
@@ -170,43 +218,63 @@ __global__ __launch_bounds__(256) void cem_train_step_kernel(const TrainParams p
     __syncthreads();
 
     // ---- backward ------------------------------------------------------------------------------------------------
+    // column sums (bias gradients) of a [Bt][U]-strided matrix: two half-sums over the even / odd rows, added in that order
+    float *colred = lds;
+    auto col_sums = [&](const float *src, const int ncol, float *dst) {
+        for (int c0 = 0; c0 < ncol; c0 += 128) {
+            const int c = c0 + (tid & 127), half = tid >> 7;
+            float a = 0.f;
+            if (c < ncol) {
+#pragma unroll 8
+                for (int r = half; r < Bt; r += 2) a += src[r * U + c];
+            }
+            colred[tid] = a;
+            __syncthreads();
+            if (tid < 128 && c < ncol) dst[c] = colred[tid] + colred[tid + 128];
+            __syncthreads();
+        }
+    };
     wg_gemm(U, O, Bt, hL, 1, U, dmu, U, 1, [&](int u, int n, float v) { G[oWmu + (size_t)u * O + n] = v; }, lds);
     wg_gemm(U, O, Bt, hL, 1, U, dv, U, 1, [&](int u, int n, float v) { G[oWv + (size_t)u * O + n] = v; }, lds);
-    for (int c = tid; c < O; c += 256) {
-        float a = 0.f, b = 0.f;
-        for (int r = 0; r < Bt; ++r) { a += dmu[r * U + c]; b += dv[r * U + c]; }
-        G[obmu + c] = a; G[obv + c] = b;
-    }
-    // dh_L = dmu Wmu^T + dv Wvar^T
+    col_sums(dmu, O, G + obmu);
+    col_sums(dv, O, G + obv);
+    // dh_L = (dmu Wmu^T + dv Wvar^T) * relu'(h_L): the relu mask rides in the epilogue of the GEMM that completes dh
     wg_gemm(Bt, U, O, dmu, U, 1, W + oWmu, 1, O, [&](int r, int n, float v) { dha[r * U + n] = v; }, lds);
-    wg_gemm(Bt, U, O, dv, U, 1, W + oWv, 1, O, [&](int r, int n, float v) { dha[r * U + n] += v; }, lds);
+    wg_gemm(Bt, U, O, dv, U, 1, W + oWv, 1, O, [&](int r, int n, float v) { dha[r * U + n] = hL[r * U + n] > 0.f ? dha[r * U + n] + v : 0.f; }, lds);
     float *dcur = dha, *dnext = dhb;
     for (int l = L - 1; l >= 0; --l) {
-        const float *hout = hs + (size_t)l * CEM_TB * U;
         const float *hin = l == 0 ? xs : hs + (size_t)(l - 1) * CEM_TB * U;
         const int in = l == 0 ? D : U;
-        for (int e = tid; e < Bt * U; e += 256) dcur[e] = hout[e] > 0.f ? dcur[e] : 0.f;     // relu'
-        __syncthreads();
         wg_gemm(in, U, Bt, hin, 1, U, dcur, U, 1, [&](int i, int n, float v) { G[offW(l) + (size_t)i * U + n] = v; }, lds);
-        for (int c = tid; c < U; c += 256) {
-            float a = 0.f;
-            for (int r = 0; r < Bt; ++r) a += dcur[r * U + c];
-            G[offb(l) + c] = a;
-        }
+        col_sums(dcur, U, G + offb(l));
         if (l > 0) {
-            wg_gemm(Bt, U, U, dcur, U, 1, W + offW(l), 1, U, [&](int r, int n, float v) { dnext[r * U + n] = v; }, lds);
+            wg_gemm(Bt, U, U, dcur, U, 1, W + offW(l), 1, U, [&](int r, int n, float v) { dnext[r * U + n] = hin[r * U + n] > 0.f ? v : 0.f; }, lds);
             float *t = dcur; dcur = dnext; dnext = t;
         }
     }
-    __syncthreads();
+}
 
-    // ---- Adam with clipvalue (mlp_ensemble.py:113-117,143-144) ---------------------------------------------------------
-    float *Mo = p.Mo + (size_t)m * p.nat, *Vo = p.Vo + (size_t)m * p.nat;
-    for (uint32_t e = tid; e < p.nat; e += 256) {
-        const float g = fminf(fmaxf(G[e], -p.clip), p.clip);
-        const float mo = Mo[e] + (g - Mo[e]) * (1.0f - p.beta1);
-        const float vo = Vo[e] + (g * g - Vo[e]) * (1.0f - p.beta2);
-        Mo[e] = mo; Vo[e] = vo;
-        W[e] = W[e] - p.lr_t * mo / (sqrtf(vo) + p.eps);
+// ---- Adam with clipvalue (mlp_ensemble.py:113-117,143-144), every member's parameters in one grid ---------------------
+__global__ __launch_bounds__(256) void cem_adam_kernel(const TrainParams p)
+{
+    const size_t n = (size_t)p.E * p.nat, n4 = n / 4;
+    const float ob1 = 1.0f - p.beta1, ob2 = 1.0f - p.beta2;
+    auto upd = [&](float g, float &mo, float &vo, float &w) {
+        g = fminf(fmaxf(g, -p.clip), p.clip);
+        mo = mo + (g - mo) * ob1;
+        vo = vo + (g * g - vo) * ob2;
+        w = w - p.lr_t * mo / (sqrtf(vo) + p.eps);
+    };
+    float4 *W4 = reinterpret_cast<float4 *>(p.W), *M4 = reinterpret_cast<float4 *>(p.Mo), *V4 = reinterpret_cast<float4 *>(p.Vo);
+    const float4 *G4 = reinterpret_cast<const float4 *>(p.grad);
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (size_t)gridDim.x * 256) {
+        const float4 g = G4[e];
+        float4 mo = M4[e], vo = V4[e], w = W4[e];
+        upd(g.x, mo.x, vo.x, w.x); upd(g.y, mo.y, vo.y, w.y); upd(g.z, mo.z, vo.z, w.z); upd(g.w, mo.w, vo.w, w.w);
+        M4[e] = mo; V4[e] = vo; W4[e] = w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t e = n4 * 4 + threadIdx.x;
+        upd(p.grad[e], p.Mo[e], p.Vo[e], p.W[e]);
     }
 }
