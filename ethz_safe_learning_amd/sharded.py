@@ -18,14 +18,15 @@ from __future__ import annotations
 
 
 class ShardedCemDriver:
-    def __init__(self, backend, iterations, world_size=1, group=None):
+    def __init__(self, backend, iterations, world_size=1, group=None, always_exchange=False):
         self.backend = backend
         self.iterations = iterations
         self.world_size = world_size
         self.group = group
+        self.always_exchange = always_exchange      # issue the collective even for one rank (exercises RCCL on a one-GPU box)
 
     def exchange(self):
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.always_exchange:
             return
         import contextlib
         import torch.distributed as dist

@@ -51,3 +51,41 @@ def test_two_ranks_on_one_gpu_match_single_rank():
             ra, rs, rit = out[rank][call]
             np.testing.assert_array_equal(ra, a)
             assert rs == sc and rit == it
+
+
+def _rccl_worker(_index, port, out):
+    import torch
+    import torch.distributed as dist
+    from tests import helpers as hp
+    from ethz_safe_learning_amd.sharded import ShardedCemDriver
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        pb = hp.make_problem(seed=82)
+        _, pcfg = hp.configs(pb, N=512, H=10, P=5, E=5, k=51, I=3, variant='cem', noise=0.02)
+        pl = hp.make_planner(pb, pcfg)
+        drv = ShardedCemDriver(pl, 3, world_size=1, always_exchange=True)
+        res = []
+        for call in range(2):
+            res.append(drv.plan(pb['state'], seed=5, call=call))
+        ref = [pl.plan(pb['state'], seed=5, call=call) for call in range(2)]
+        out['res'] = (res, ref)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_exchange_on_the_planner_stream_single_rank():
+    """The bench's N>1 leg uses backend 'nccl' (= RCCL).  One GPU allows one RCCL rank, so this runs the real collective
+    (all_gather_into_tensor of the score shard, issued with the planner's stream current) with world_size 1 and checks
+    the stepwise plan through it equals the captured-graph plan."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.get_context('spawn').Manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_worker, args=(port, out), nprocs=1, join=True)
+    res, ref = out['res']
+    for (a, sc, it), (ra, rs, rit) in zip(res, ref):
+        np.testing.assert_array_equal(a, ra)
+        assert sc == rs and it == rit
