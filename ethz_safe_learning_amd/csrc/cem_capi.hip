@@ -515,7 +515,7 @@ int enqueue_rollout(cem_planner *h, int it)
     ReduceParams qp{}; qp.ret = rp.ret; qp.costs = rp.costs; qp.scores = (float *)(ws + l.scores_local); qp.ctrl = sp.ctrl;
     qp.Nloc = d.Nloc; qp.P = d.P; qp.H = d.H; qp.variant = h->cfg.variant; qp.check_done = 1;
     qp.alpha = h->alpha; qp.beta = h->beta; qp.thr = h->cfg.posterior_mean_threashold;
-    hipLaunchKernelGGL(cem_reduce_kernel, dim3((d.Nloc + 255) / 256), dim3(256), 0, h->stream, qp);
+    hipLaunchKernelGGL(cem_reduce_kernel, dim3((d.Nloc + 63) / 64), dim3(CEM_REDUCE_THREADS), 0, h->stream, qp);
     HIPCHK(hipGetLastError());
     return CEM_OK;
 }

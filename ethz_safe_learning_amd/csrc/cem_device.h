@@ -566,25 +566,60 @@ struct ReduceParams {
     float alpha, beta, thr;
 };
 
-__global__ __launch_bounds__(256) void cem_reduce_kernel(const ReduceParams p)
+// One block = 64 candidates x 16 waves.  Wave w counts the particle costs of steps t = w, w+16, ... (byte loads,
+// coalesced over the 64 candidates, 8 in flight per lane); wave 0 also forms the particle mean in the reference's
+// order q = 0..P-1.  Counts are small integers, exact in the reference's fp32 sums as well.
+#define CEM_REDUCE_THREADS 1024
+__global__ __launch_bounds__(CEM_REDUCE_THREADS) void cem_reduce_kernel(const ReduceParams p)
 {
+    __shared__ int32_t unsafe_w[16][64];
     if (p.check_done && p.ctrl->done) return;
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= p.Nloc) return;
-    float sum = 0.f;
-    for (int q = 0; q < p.P; ++q) sum = sum + p.ret[(size_t)q * p.Nloc + n];
-    float score = sum / (float)p.P;                                    // reduce_mean over particles
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const bool live = n < p.Nloc;
+    const int nn = live ? n : p.Nloc - 1;
+    int32_t unsafe = 0;
     if (p.variant == 1) {                                              // safe_cem_mpc.py:90-96,110-120
-        bool safe = true;
         const float denom = (p.alpha + p.beta) + (float)p.P;
         const size_t Bloc = (size_t)p.P * p.Nloc;
-        for (int t = 0; t < p.H; ++t) {
-            float cnt = 0.f;
-            for (int q = 0; q < p.P; ++q) cnt = cnt + (float)p.costs[(size_t)t * Bloc + (size_t)q * p.Nloc + n];
-            const float post = (p.alpha + cnt) / denom;
-            safe = safe && (post <= p.thr);
+        for (int t = w; t < p.H; t += 16) {
+            const uint8_t *c = p.costs + (size_t)t * Bloc + nn;
+            uint32_t cnt = 0;
+            int q = 0;
+            for (; q + 8 <= p.P; q += 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = c[(size_t)(q + j) * p.Nloc];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cnt += v[j];
+            }
+            for (; q < p.P; ++q) cnt += c[(size_t)q * p.Nloc];
+            const float post = (p.alpha + (float)cnt) / denom;
+            unsafe |= (post <= p.thr) ? 0 : 1;
         }
-        score = score - (safe ? 0.0f : 1.0f) * 100.0f;
+        unsafe_w[w][lane] = unsafe;
+    }
+    float sum = 0.f;
+    if (w == 0) {
+        const float *r = p.ret + nn;
+        int q = 0;
+        for (; q + 8 <= p.P; q += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = r[(size_t)(q + j) * p.Nloc];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum = sum + v[j];
+        }
+        for (; q < p.P; ++q) sum = sum + r[(size_t)q * p.Nloc];
+    }
+    __syncthreads();
+    if (w != 0 || !live) return;
+    float score = sum / (float)p.P;                                    // reduce_mean over particles
+    if (p.variant == 1) {
+        int32_t u = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) u |= unsafe_w[i][lane];
+        score = score - (u ? 1.0f : 0.0f) * 100.0f;
     }
     p.scores[n] = score;
 }
