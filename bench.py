@@ -23,6 +23,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
+SHADER_CLOCK_HZ = 2.4e9            # MI355X peak engine clock (MI355X_MICROARCH.md)
 
 
 def cpu_baseline(pb, obs, act, K, N, H, I, k, budget_s=25.0):
@@ -136,10 +137,14 @@ def main():
     avg_ms = roll_ms / max(roll_n, 1)
     achieved = flops_launch / (avg_ms * 1e-3) / 1e12
 
+    mfma_util = None
     traffic = None                 # HBM-side bytes per rollout launch from the committed rocprofv3 TCC passes (same workload)
     tpath = os.path.join(ROOT, 'profiles', 'traffic_b2.json')
     if G == 1 and args.n_per_gpu == 2000 and os.path.exists(tpath):
-        traffic = json.load(open(tpath))['hbm_bytes_per_launch']
+        prof = json.load(open(tpath))
+        traffic = prof['hbm_bytes_per_launch']
+        # MFMA-pipe utilisation: PMC busy cycles per launch (committed rocprofv3 pass) over 1024 SIMDs x this run's launch time
+        mfma_util = prof.get('sq_valu_mfma_busy_cycles_per_launch', 0.0) / (1024 * avg_ms * 1e-3 * SHADER_CLOCK_HZ) or None
 
     plans_per_s = args.steps / dt
     b2_equiv = plans_per_s * (N / 2000.0)
@@ -153,7 +158,7 @@ def main():
                    'hip_graph': bool(cfg.use_graph), 'parallelism': 'candidates sharded x%d, 1 all-gather of scores/iter' % G},
         'candidate_trajectory_steps_per_s': plans_per_s * I * N * H,
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+                     'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'mfma_busy_frac': mfma_util,
                      'kernel': 'cem_rollout_kernel', 'avg_launch_ms': avg_ms, 'launches_timed': roll_n,
                      'algorithmic_flops_per_launch': flops_launch},
     }
