@@ -26,7 +26,6 @@ class CemMpc(MpcPolicy):
         self.device = device
         self.use_graph = use_graph
         self._planner = None
-        self._model_version = None
         self.last_score = None
         self.last_iterations = None
 

@@ -2,7 +2,6 @@
 """Rollout-kernel time and roofline fraction at the BASELINE configs (B1..B4; B5's per-GPU shard = 8192 candidates).
 The bench line is B2 only (bench.py); this is the table in DESIGN.md.  usage: python scripts/sweep_configs.py"""
 import json, os, sys, time
-import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ethz_safe_learning_amd import CemPlanner, PlannerConfig, synthetic

@@ -44,10 +44,11 @@ def test_tune_cem_policy_grid_reuses_handles(tmp_path):
     assert [r['n_elite'] for r in res[:2]] == [round(0.05 * 150), 15]
     grown = planner.planner_cache_info()['size'] - before
     assert 8 <= grown <= 9                                     # 8 distinct CemMpc shapes (+ the training run's safe policy)
-    res2 = tune.grid_search.__wrapped__ if hasattr(tune.grid_search, '__wrapped__') else None
-    # the same shape again -> no new handle
-    from ethz_safe_learning_amd.simba.policies import CemMpc
-    n0 = planner.planner_cache_info()['size']
     import glob
     assert glob.glob(os.path.join(str(tmp_path), 'tune_*', 'training_data', 'grid_search.json'))
+    # the same grid again -> every shape is already cached, no new handle
+    n0 = planner.planner_cache_info()['size']
+    tune.main(['--config_dir', os.path.join(ROOT, 'ethz_safe_learning_amd', 'config'), '--config_basename', 'smoke.yaml',
+               '--log_dir', str(tmp_path), '--name', 'tune2', '--seed', '1',
+               '--log_level', 'WARNING', '--eval_steps', '60', '--eval_episode_length', '60', '--quick'])
     assert planner.planner_cache_info()['size'] == n0
