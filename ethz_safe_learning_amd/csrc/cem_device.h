@@ -327,6 +327,8 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
         d_prev = dn; c_prev = cn; } } while (0)
 
     f4 hB[CEM_NG][RC];
+    f4 nb0 = *reinterpret_cast<const f4 *>(bias_h + 16 * (2 * w) + 4 * q);            // layer-0 bias, own blocks 2w, 2w+1
+    f4 nb1 = *reinterpret_cast<const f4 *>(bias_h + 16 * (2 * w + 1) + 4 * q);
 #ifdef CEM_STAMPS
     long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev_ = (long long)__builtin_amdgcn_s_memtime();
@@ -334,33 +336,45 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
 
     for (int t = -1; t < H; ++t) {
         if (t >= 0) {
-            // ---- hidden layers: h = relu(h W + b)  (mlp_ensemble.py:18-22) -----------------------------
-            for (int l = 0; l < p.L; ++l) {
-                // the accumulators start at the bias (x W + b with b added first: same sum, one rounding order apart)
-                const f4 b0 = *reinterpret_cast<const f4 *>(bias_h + l * CEM_U + 16 * (2 * w) + 4 * q);
-                const f4 b1 = *reinterpret_cast<const f4 *>(bias_h + l * CEM_U + 16 * (2 * w + 1) + 4 * q);
+            // ---- dense layers: h = relu(h W + b)  (mlp_ensemble.py:18-22).  The accumulators start at the bias
+            // (x W + b with b added first: same sum, one rounding order apart); the bias of the NEXT layer is requested a
+            // whole stage ahead of its use.  Layer 0 is peeled out of the loop: with both stage shapes inside one runtime
+            // loop the compiler merges their weight-ring registers at the join with moves behind an s_waitcnt vmcnt(0),
+            // i.e. drains the prefetch ring once per step.
+#define CEM_RELU_PUBLISH() do { \
+                _Pragma("unroll") for (int c = 0; c < RC; ++c) { \
+                    f4 h0 = acc0[c], h1 = acc1[c]; \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) { h0[r] = fmaxf(h0[r], 0.f); h1[r] = fmaxf(h1[r], 0.f); } \
+                    *reinterpret_cast<f4 *>(smem + xw + ((c * CEM_NG + 2 * w) * 64 + lane) * 16) = h0; \
+                    *reinterpret_cast<f4 *>(smem + xw + ((c * CEM_NG + 2 * w + 1) * 64 + lane) * 16) = h1; \
+                    hB[0][c] = h0; hB[1][c] = h1;         /* own blocks of the next stage: no LDS round trip */ \
+                } \
+                xw ^= XB; } while (0)
+#define CEM_NEXT_BIAS(LN) do { \
+                nb0 = *reinterpret_cast<const f4 *>(bias_h + (LN) * CEM_U + 16 * (2 * w) + 4 * q); \
+                nb1 = *reinterpret_cast<const f4 *>(bias_h + (LN) * CEM_U + 16 * (2 * w + 1) + 4 * q); } while (0)
+            {
                 f4 acc0[RC], acc1[RC];
 #pragma unroll
-                for (int c = 0; c < RC; ++c) { acc0[c] = b0; acc1[c] = b1; }
+                for (int c = 0; c < RC; ++c) { acc0[c] = nb0; acc1[c] = nb1; }
+                CEM_NEXT_BIAS(p.L > 1 ? 1 : 0);
                 // stage input = previous stage's output buffer = xw ^ XB (the previous stage toggled xw after writing)
-                if (l == 0) {
-                    cem_mfma_stage<RC, 4 * NFW, NFW, true, true>(acc0, acc1, hB, wq, smem, xw ^ XB, lane, w);
-                    CEM_BOOKKEEP(t - 1);                  // the barrier inside the stage published step t-1's scorer terms
-                } else {
-                    cem_mfma_stage<RC, CEM_NG, 2, false, true>(acc0, acc1, hB, wq, smem, xw ^ XB, lane, w);
-                }
-#pragma unroll
-                for (int c = 0; c < RC; ++c) {
-                    f4 h0 = acc0[c], h1 = acc1[c];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { h0[r] = fmaxf(h0[r], 0.f); h1[r] = fmaxf(h1[r], 0.f); }
-                    *reinterpret_cast<f4 *>(smem + xw + ((c * CEM_NG + 2 * w) * 64 + lane) * 16) = h0;
-                    *reinterpret_cast<f4 *>(smem + xw + ((c * CEM_NG + 2 * w + 1) * 64 + lane) * 16) = h1;
-                    hB[0][c] = h0; hB[1][c] = h1;         // own blocks of the next stage: no LDS round trip
-                }
-                xw ^= XB;
-                CEM_STAMP(l == 0 ? 0 : 1);
+                cem_mfma_stage<RC, 4 * NFW, NFW, true, true>(acc0, acc1, hB, wq, smem, xw ^ XB, lane, w);
+                CEM_BOOKKEEP(t - 1);                      // the barrier inside the stage published step t-1's scorer terms
+                CEM_RELU_PUBLISH();
+                CEM_STAMP(0);
             }
+            for (int l = 1; l < p.L; ++l) {
+                f4 acc0[RC], acc1[RC];
+#pragma unroll
+                for (int c = 0; c < RC; ++c) { acc0[c] = nb0; acc1[c] = nb1; }
+                CEM_NEXT_BIAS(l + 1 < p.L ? l + 1 : 0);
+                cem_mfma_stage<RC, CEM_NG, 2, false, true>(acc0, acc1, hB, wq, smem, xw ^ XB, lane, w);
+                CEM_RELU_PUBLISH();
+                CEM_STAMP(1);
+            }
+#undef CEM_RELU_PUBLISH
+#undef CEM_NEXT_BIAS
         }
 
         // ---- heads (mlp_ensemble.py:33-34,189-193), state update (transition_model.py:75), scorer partials
