@@ -184,14 +184,23 @@ __host__ __device__ inline int cem_perm_l0(int w, int nfw, int phi)      // laye
 // MFMAs.  Every stage consumes a multiple of 4 groups (layer 0 is zero-padded to 4*NFW groups on the host), so the
 // slot of stage-local group phi is the compile-time constant phi & 3: no register moves, no branches.
 struct WRing {
-    const f4 *base;          // wave-uniform stream base: the per-lane part is a constant offset, so the loads take the
-    int lane;                // scalar-base form and no VALU address arithmetic sits in the MFMA stream
+    __amdgpu_buffer_rsrc_t rsrc;   // this wave's weight stream as a buffer: group offset in an SGPR, lane offset in one constant
+    int voff;                      // VGPR -> no per-group VALU address arithmetic inside the MFMA stream
     int n, pos;
     AGroup slot[4];
-    __device__ __forceinline__ AGroup ld(int g) const { AGroup r; r.a = base[g * 128 + lane]; r.b = base[g * 128 + 64 + lane]; return r; }
+    __device__ __forceinline__ AGroup ld(int g) const
+    {
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        AGroup r;
+        const u4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, g * 2048, 0);
+        const u4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 1024, g * 2048, 0);
+        r.a = __builtin_bit_cast(f4, a); r.b = __builtin_bit_cast(f4, b);
+        return r;
+    }
     __device__ __forceinline__ void init(const f4 *b, int lane_, int n_)
     {
-        base = b; lane = lane_; n = n_;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f4 *>(b), 0, n_ * 2048, 0x00020000);
+        voff = lane_ * 16; n = n_;
         slot[0] = ld(0); slot[1] = ld(1 % n_); slot[2] = ld(2 % n_); slot[3] = slot[2];
         pos = 3 % n_;
     }
@@ -263,7 +272,11 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
     const PhiloxKey key = cem_key(p.ctrl);
 
     WRing wq;
-    wq.init(p.wpack + (size_t)td.member * p.member_stride_f4 + p.wave_off_f4[w], lane, (int)p.wave_groups[w]);
+    {
+        // descriptor inputs made provably wave-uniform (the tile descriptor load and the wave id are uniform in fact)
+        const int member_u = __builtin_amdgcn_readfirstlane(td.member);
+        wq.init(p.wpack + (size_t)member_u * p.member_stride_f4 + p.wave_off_f4[w], lane, (int)p.wave_groups[w]);
+    }
 
     const float *bias_h = p.bias_h + (size_t)td.member * p.L * CEM_U;
     const float *bias_mu = p.bias_mu + (size_t)td.member * CEM_U;
