@@ -158,15 +158,62 @@ void build_plan_tiles(const Dims &d, int rc, std::vector<Tile6> &out)
     out.swap(perm);
 }
 
+// ---- tile-size choice ------------------------------------------------------------------------------------------------
+// A tile is 16*rc rows of one member; a CU keeps as many workgroups resident as their registers allow.  fp32 MFMA and
+// VALU work add up on a SIMD whichever wave they come from, so a co-resident workgroup cannot hide arithmetic — but it
+// does hide the stalls (barrier skew, LDS and L2 latency at the stage boundaries), and that is worth 8-20 % per chunk.
+// Cost of one 16-row chunk for the whole horizon, in units of the measured B-config sweeps (ms at H = 30, MI355X, round 1:
+// profiles/r01_sweep_chunks.txt): `solo` with one workgroup on the CU, `shared` with two or more.  Larger tiles re-use each
+// streamed weight group for more rows (less L2 traffic); smaller tiles pack the CUs more evenly and co-reside more easily.
+static const double kChunkSolo[2][4] = {{0.192, 0.168, 0.159, 0.157}, {1.25, 1.056, 1.02, 1.006}};
+static const double kChunkShared[2][4] = {{0.153, 0.148, 0.1445, 0.1445}, {1.00, 0.97, 0.94, 0.93}};
+static const int kResidentStatic[2][4] = {{3, 2, 2, 2}, {2, 1, 1, 1}};     // from the kernels' VGPR counts (155/181/221/249, 229/275/334/408)
+
+template <int RC, int NFW>
+int query_resident()
+{
+    int n = 0;
+    const size_t lds = (size_t)2 * RC * CEM_NG * 1024 + CEM_PART_FLOATS * 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cem_rollout_kernel<RC, NFW, 0>, 256, lds) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+// workgroups of the <rc, nfw> hot kernel one CU keeps resident: asked from the runtime, static table without a device
+int resident_workgroups(int nfw, int rc)
+{
+    static int cache[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};
+    int &c = cache[nfw - 1][rc - 1];
+    if (c < 0) {
+        int n = 0;
+#define CEM_CASE(R, F) if (rc == R && nfw == F) n = query_resident<R, F>();
+        CEM_CASE(1, 1) CEM_CASE(2, 1) CEM_CASE(3, 1) CEM_CASE(4, 1)
+        CEM_CASE(1, 2) CEM_CASE(2, 2) CEM_CASE(3, 2) CEM_CASE(4, 2)
+#undef CEM_CASE
+        c = n > 0 ? n : kResidentStatic[nfw - 1][rc - 1];
+    }
+    return c;
+}
+
+double tile_plan_cost(const Dims &d, int rc, size_t n_tiles)
+{
+    const int occ = resident_workgroups(d.NFW, rc);
+    const long per_cu = (long)((n_tiles + 255) / 256);
+    const long full = per_cu / occ, rem = per_cu % occ;
+    auto c = [&](long resident) { return resident >= 2 ? kChunkShared[d.NFW - 1][rc - 1] : kChunkSolo[d.NFW - 1][rc - 1]; };
+    return (double)rc * ((double)(full * occ) * c(occ) + (double)rem * c(rem));
+}
+
 int auto_chunks(const Dims &d)
 {
-    // makespan model: 256 CUs, tile cost ~ (rc + fixed overhead of barriers/epilogue)
     int best = 1; double bestc = 1e30;
     for (int rc = 1; rc <= 4; ++rc) {
         std::vector<Tile6> t; build_plan_tiles(d, rc, t);
-        const double waves = std::ceil((double)t.size() / 256.0);
-        const double cost = waves * (rc + 0.35);
-        if (cost < bestc - 1e-9) { bestc = cost; best = rc; }
+        const double cost = tile_plan_cost(d, rc, t.size());
+        // rc ascends: a cost within 0.5 % of the best so far goes to the larger tile (fewer workgroups, less weight traffic)
+        if (cost <= bestc * 1.005) { best = rc; bestc = std::min(bestc, cost); }
     }
     return best;
 }
@@ -296,6 +343,21 @@ int cem_plan_tiles_host(const cem_config_t *cfg, int32_t *rc_out, int32_t *n_til
     if (tiles_out) {
         if ((int)t.size() > max_tiles) return CEM_ERR_INVALID_ARG;
         std::memcpy(tiles_out, t.data(), t.size() * sizeof(Tile6));
+    }
+    return CEM_OK;
+}
+
+int cem_rollout_residency(int32_t chunks_per_tile, int32_t input_blocks_per_wave, int32_t *table_out, int32_t *runtime_out)
+{
+    if (chunks_per_tile < 1 || chunks_per_tile > 4 || input_blocks_per_wave < 1 || input_blocks_per_wave > 2) return CEM_ERR_INVALID_ARG;
+    if (table_out) *table_out = kResidentStatic[input_blocks_per_wave - 1][chunks_per_tile - 1];
+    if (runtime_out) {
+        int n = 0;
+#define CEM_CASE(R, F) if (chunks_per_tile == R && input_blocks_per_wave == F) n = query_resident<R, F>();
+        CEM_CASE(1, 1) CEM_CASE(2, 1) CEM_CASE(3, 1) CEM_CASE(4, 1)
+        CEM_CASE(1, 2) CEM_CASE(2, 2) CEM_CASE(3, 2) CEM_CASE(4, 2)
+#undef CEM_CASE
+        *runtime_out = n;
     }
     return CEM_OK;
 }

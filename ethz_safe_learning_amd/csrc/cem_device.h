@@ -206,6 +206,7 @@ struct WRing {
     }
 };
 
+#define CEM_LDS_AHEAD 1
 #define CEM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // One dense stage for this wave: acc{0,1}[c] += W^T-groups . hB.  hB[0..NOWN-1] (the wave's own blocks) are already
@@ -223,14 +224,19 @@ __device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], f
         // pin the prefetch here: unpinned, the machine scheduler sinks the load to just before its use and every
         // group of MFMAs eats a full L2 round trip
         __builtin_amdgcn_sched_barrier(0);
-        if (EXCHANGE && P == 1) {
-            __syncthreads();                              // every wave's blocks of the previous stage are in LDS
+        if (EXCHANGE && P >= 1) {
+            // the other waves' blocks are read just in time, CEM_LDS_AHEAD groups before their MFMAs: all of them at once
+            // is 24*RC live registers from group 1 on, which at RC = 3 pushes the kernel over the 256 architectural VGPRs
+            if (P == 1) __syncthreads();                  // every wave's blocks of the previous stage are in LDS
 #pragma unroll
             for (int Q = NOWN; Q < KF; ++Q) {
-                const int F = L0IN ? cem_perm_l0(w, KF / 4, Q) : cem_perm_hidden(w, Q);
+                const bool now = (P == 1) ? (Q <= 1 + CEM_LDS_AHEAD) : (Q == P + CEM_LDS_AHEAD);
+                if (now) {
+                    const int F = L0IN ? cem_perm_l0(w, KF / 4, Q) : cem_perm_hidden(w, Q);
 #pragma unroll
-                for (int c = 0; c < RC; ++c)
-                    hB[Q][c] = *reinterpret_cast<const f4 *>(smem + xr + ((c * CEM_NG + F) * 64 + lane) * 16);
+                    for (int c = 0; c < RC; ++c)
+                        hB[Q][c] = *reinterpret_cast<const f4 *>(smem + xr + ((c * CEM_NG + F) * 64 + lane) * 16);
+                }
             }
         }
         const AGroup g = wq.slot[P & 3];

@@ -126,6 +126,10 @@ int cem_pack_weights_host(const cem_config_t *cfg, const float *blob, float *pac
 int cem_plan_tiles_host(const cem_config_t *cfg, int32_t *chunks_per_tile_out, int32_t *n_tiles_out,
                         int32_t *tiles_out /* [n_tiles][6]: row_base,cnt,member,act_base,noise_row_base,s0_base */, int32_t max_tiles);
 
+/* diagnostic: workgroups of the rollout kernel for (chunks_per_tile, obs+act <= 64 ? 1 : 2 input blocks per wave) one CU keeps
+ * resident — what the tile-size choice assumes (`table_out`) and what the HIP runtime reports (`runtime_out`, 0 without a device). */
+int cem_rollout_residency(int32_t chunks_per_tile, int32_t input_blocks_per_wave, int32_t *table_out, int32_t *runtime_out);
+
 /* lifecycle.  `workspace` is device memory of >= cem_workspace_bytes(cfg), 256-B aligned; `hip_stream` a hipStream_t (NULL = default). */
 int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspace_bytes, void *hip_stream, cem_planner_t **out);
 int cem_planner_destroy(cem_planner_t *h);

@@ -135,9 +135,19 @@ def test_tiles_partition_rows_and_respect_member_boundaries(built_lib, kw):
     _check_tiles(cfg, rc, tiles)
 
 
-def test_b2_uses_three_chunk_tiles_on_at_most_256_workgroups(built_lib):
-    rc, tiles = plan_tiles(_cfg())
-    assert rc == 3 and len(tiles) <= 256
+def test_tile_size_choice_follows_the_measured_cost_model(built_lib):
+    """cem_capi.hip auto_chunks: max chunks per CU x per-chunk cost (cheaper when >= 2 workgroups share the CU).  Without a
+    device the residency table is the static one; tests/test_gpu_parity.py checks it against the runtime's answer."""
+    rc, tiles = plan_tiles(_cfg())                                                  # B2: 625 one-chunk tiles, <= 3 per CU
+    assert rc == 1 and len(tiles) == 625
+    rc, tiles = plan_tiles(_cfg(n_samples=500, horizon=25, n_elite=50))             # B1: one chunk per CU
+    assert rc == 1 and len(tiles) <= 256
+    rc, tiles = plan_tiles(_cfg(ensemble_size=16, particles=16, n_samples=8192, n_elite=819))   # B3: 8 four-chunk tiles per CU, 2 resident
+    assert rc == 4 and len(tiles) == 2048
+    rc, tiles = plan_tiles(_cfg(n_samples=8192, n_elite=819))                       # B5 shard: exactly 5 two-chunk tiles per CU
+    assert rc == 2 and len(tiles) == 1280
+    rc, tiles = plan_tiles(_cfg(ensemble_size=15, particles=45, n_samples=500, n_elite=20, horizon=8))   # shipped safe_cem_mpc
+    assert rc == 3
 
 
 def test_xcd_order_groups_members(built_lib):

@@ -268,6 +268,19 @@ def test_early_stop_and_call_counter():
     np.testing.assert_array_equal(a, c)          # and (seed, call) reproduces
 
 
+def test_residency_table_matches_the_runtime():
+    """The tile-size choice (cem_capi.hip auto_chunks) prices co-resident workgroups; its static residency table (used by
+    the GPU-less host helper) must be what the runtime reports for the compiled kernels."""
+    import ctypes as C
+    from ethz_safe_learning_amd import _capi
+    lib = _capi.load()
+    for nfw in (1, 2):
+        for rc in (1, 2, 3, 4):
+            tab, run = C.c_int32(), C.c_int32()
+            _capi.check(lib.cem_rollout_residency(rc, nfw, C.byref(tab), C.byref(run)), 'cem_rollout_residency')
+            assert run.value >= 1 and tab.value == run.value, (nfw, rc, tab.value, run.value)
+
+
 def test_errors_are_loud():
     from ethz_safe_learning_amd import CemPlanner
     from ethz_safe_learning_amd._capi import CemError
