@@ -590,10 +590,13 @@ int enqueue_select(cem_planner *h, int it)
     p.musig = (float *)(ws + l.musig); p.ctrl = (CtrlBlock *)(ws + l.ctrl); p.elite_idx = (int32_t *)(ws + l.elite);
     p.N = d.N; p.k = d.k; p.HA = d.H * d.A; p.A = d.A; p.check_done = 1;
     p.smoothing = h->cfg.smoothing; p.threshold = h->cfg.stddev_threshold;
-    const size_t lds = (size_t)((d.k + 3) & ~3) * 4 + (size_t)d.H * d.A * 4;
+    size_t lds = (size_t)((d.k + 3) & ~3) * 4 + (size_t)2 * d.H * d.A * 4;
+    const bool cache = lds + (size_t)d.N * 4 <= 48 * 1024;          // scores staged in LDS (with the ~7 KB of static arrays: < 64 KB)
+    if (cache) lds += (size_t)d.N * 4;
     size_t e0 = 0;
     if (h->timing) { e0 = h->ev_kind.size() * 2; h->ev_kind.push_back({(int)e0, 1}); hipEventRecord(get_event(h, e0), h->stream); }
-    hipLaunchKernelGGL(cem_select_kernel, dim3(1), dim3(1024), lds, h->stream, p);
+    if (cache) hipLaunchKernelGGL(cem_select_kernel<true>, dim3(1), dim3(1024), lds, h->stream, p);
+    else hipLaunchKernelGGL(cem_select_kernel<false>, dim3(1), dim3(1024), lds, h->stream, p);
     HIPCHK(hipGetLastError());
     if (h->timing) hipEventRecord(get_event(h, e0 + 1), h->stream);
     return CEM_OK;

@@ -671,69 +671,89 @@ __device__ __forceinline__ uint32_t cem_f2key(float f)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// exclusive scan of one value per thread over a 1024-thread block; returns exclusive prefix, total via ref
-__device__ __forceinline__ uint32_t cem_block_excl_scan(uint32_t v, uint32_t *wsum /*[17]*/, uint32_t &total)
+// exclusive scans of two values per thread over a 1024-thread block (one barrier): pa, pb = sums over lower thread ids
+__device__ __forceinline__ void cem_block_excl_scan2(const uint32_t a, const uint32_t b, uint32_t (*wsum)[16], uint32_t &pa, uint32_t &pb)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t inc = v;
+    uint32_t ia = a, ib = b;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t oa = __shfl_up(ia, d), ob = __shfl_up(ib, d);
+        if (lane >= d) { ia += oa; ib += ob; }
+    }
+    if (lane == 63) { wsum[0][wv] = ia; wsum[1][wv] = ib; }
     __syncthreads();
-    if (lane == 63) wsum[wv] = inc;
-    __syncthreads();
-    if (threadIdx.x == 0) { uint32_t run = 0; for (int i = 0; i < 16; ++i) { const uint32_t x = wsum[i]; wsum[i] = run; run += x; } wsum[16] = run; }
-    __syncthreads();
-    total = wsum[16];
-    return wsum[wv] + inc - v;
+    uint32_t ba = 0, bb = 0;
+    for (int i = 0; i < wv; ++i) { ba += wsum[0][i]; bb += wsum[1][i]; }
+    pa = ba + ia - a; pb = bb + ib - b;
 }
 
-// top_k + best-so-far + moments + smoothing + early stop, one 1024-thread workgroup  (cem_mpc.py:56-67)
+// top_k + best-so-far + moments + smoothing + early stop, one 1024-thread workgroup  (cem_mpc.py:56-67).
+// One CU, so the kernel is a latency chain: the scores are staged in LDS once (CACHE; they are read by 4 radix passes, the
+// compaction and the best-of-elite), the 256-bin suffix scan of a pass is done by one wave with shuffles (2 barriers per
+// pass), gathers are issued in batches, and the two serial tails run on different waves.  All sums keep a fixed order.
+template <bool CACHE>
 __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char sel_smem[];
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t sfx[256];
-    __shared__ uint32_t wsum[17];
+    __shared__ __attribute__((aligned(16))) uint32_t hist[2][256];
+    __shared__ uint32_t wsum[2][16];
     __shared__ uint32_t sh_prefix, sh_need;
     __shared__ float red[1024];
     __shared__ float bsc[16];
     __shared__ int bpos[16];
     if (p.check_done && p.ctrl->done) return;
 
-    int32_t *elite = reinterpret_cast<int32_t *>(sel_smem);                 // [k]
-    float *colmean = reinterpret_cast<float *>(sel_smem + (size_t)((p.k + 3) & ~3) * 4);   // [HA]
     const int tid = threadIdx.x;
-    const int N = p.N, k = p.k;
+    const int N = p.N, k = p.k, HA = p.HA;
+    int32_t *elite = reinterpret_cast<int32_t *>(sel_smem);                 // [k]
+    float *colmean = reinterpret_cast<float *>(sel_smem + (size_t)((k + 3) & ~3) * 4);   // [HA]
+    float *newsig = colmean + HA;                                           // [HA] smoothed sigma
+    float *csc = newsig + HA;                                               // [N] scores (CACHE)
+
+    // old mu / sigma of the columns this thread will finish (first column block): requested now, needed at the very end
+    float old_mu = 0.f, old_sg = 0.f;
+    if (tid < HA) { old_mu = p.musig[tid]; old_sg = p.musig[HA + tid]; }
+
+    if (CACHE) {
+        for (int i0 = 0; i0 < N; i0 += 4096) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int i = i0 + j * 1024 + tid; if (i < N) v[j] = p.scores[i]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int i = i0 + j * 1024 + tid; if (i < N) csc[i] = v[j]; }
+        }
+    }
+    const float *S = CACHE ? csc : p.scores;
+    if (tid < 256) hist[1][tid] = 0;                  // pass 3 counts into hist[3 & 1]
+    __syncthreads();
 
     // ---- radix select of the k-th largest key ----------------------------------------------------------
     uint32_t prefix = 0, mask = 0, need = (uint32_t)k;
     for (int pass = 3; pass >= 0; --pass) {
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
+        const int hb = pass & 1;
         for (int i = tid; i < N; i += 1024) {
-            const uint32_t key = cem_f2key(p.scores[i]);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> (8 * pass)) & 255u], 1u);
+            const uint32_t key = cem_f2key(S[i]);
+            if ((key & mask) == prefix) atomicAdd(&hist[hb][(key >> (8 * pass)) & 255u], 1u);
         }
+        if (tid < 256) hist[hb ^ 1][tid] = 0;         // the next pass's histogram
         __syncthreads();
-        // suffix counts ge[b] = #keys in bins >= b (Hillis-Steele over the 256 bins), then the one bin with
-        // ge[b] >= need > ge[b+1] is the next byte of the k-th largest key
-        if (tid < 256) sfx[tid] = hist[tid];
-        __syncthreads();
+        // ge[b] = #keys in bins >= b; the one bin with ge[b] >= need > ge[b+1] is the next byte of the k-th largest key.
+        // Lane l of wave 0 owns bins 4l..4l+3: local suffix sums + an exclusive suffix scan of the lane totals.
+        if (tid < 64) {
+            const uint4 h = *reinterpret_cast<const uint4 *>(&hist[hb][4 * tid]);
+            const uint32_t s3 = h.w, s2 = h.z + s3, s1 = h.y + s2, s0 = h.x + s1;
+            uint32_t inc = s0;
 #pragma unroll
-        for (int d = 1; d < 256; d <<= 1) {
-            uint32_t v = 0;
-            if (tid < 256) v = sfx[tid] + ((tid + d < 256) ? sfx[tid + d] : 0u);
-            __syncthreads();
-            if (tid < 256) sfx[tid] = v;
-            __syncthreads();
-        }
-        if (tid < 256) {
-            const uint32_t ge = sfx[tid], gt = (tid < 255) ? sfx[tid + 1] : 0u;
-            if (ge >= need && gt < need) { sh_prefix = prefix | ((uint32_t)tid << (8 * pass)); sh_need = need - gt; }
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_down(inc, d); if (tid + d < 64) inc += o; }
+            const uint32_t ex = inc - s0;
+            const uint32_t ge[4] = {s0 + ex, s1 + ex, s2 + ex, s3 + ex}, gt[4] = {s1 + ex, s2 + ex, s3 + ex, ex};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (ge[j] >= need && gt[j] < need) { sh_prefix = prefix | ((uint32_t)(4 * tid + j) << (8 * pass)); sh_need = need - gt[j]; }
         }
         __syncthreads();
         prefix = sh_prefix; need = sh_need; mask |= 0xFFu << (8 * pass);
-        __syncthreads();
     }
     const uint32_t T = prefix;          // key of the k-th largest score; `need` ties are taken, lowest index first
 
@@ -741,15 +761,14 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
     const int C = (N + 1023) / 1024;
     const int beg = tid * C, end = (beg + C < N) ? beg + C : N;
     uint32_t ngt = 0, neq = 0;
-    for (int i = beg; i < end; ++i) { const uint32_t key = cem_f2key(p.scores[i]); ngt += key > T; neq += key == T; }
-    uint32_t tot_gt, tot_eq;
-    const uint32_t pre_gt = cem_block_excl_scan(ngt, wsum, tot_gt);
-    const uint32_t pre_eq = cem_block_excl_scan(neq, wsum, tot_eq);
+    for (int i = beg; i < end; ++i) { const uint32_t key = cem_f2key(S[i]); ngt += key > T; neq += key == T; }
+    uint32_t pre_gt, pre_eq;
+    cem_block_excl_scan2(ngt, neq, wsum, pre_gt, pre_eq);
     {
         uint32_t eqr = pre_eq;
         uint32_t pos = pre_gt + (pre_eq < need ? pre_eq : need);
         for (int i = beg; i < end; ++i) {
-            const uint32_t key = cem_f2key(p.scores[i]);
+            const uint32_t key = cem_f2key(S[i]);
             bool take = key > T;
             if (key == T) { take = eqr < need; ++eqr; }
             if (take) { elite[pos] = i; p.elite_idx[pos] = i; ++pos; }
@@ -758,10 +777,11 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
     __syncthreads();
 
     // ---- best of elite: max score, first (= lowest index) among exact ties  (cem_mpc.py:57-60) -------------
+    // per-wave candidates now; the final combine and the update of best-so-far run on wave 1 at the very end
     {
         float bs = -__builtin_inff(); int bp = 0x7fffffff;
         for (int e = tid; e < k; e += 1024) {
-            const float sc = p.scores[elite[e]];
+            const float sc = S[elite[e]];
             if (bp == 0x7fffffff || sc > bs) { bs = sc; bp = e; }
         }
 #pragma unroll
@@ -770,34 +790,34 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
             if (op != 0x7fffffff && (bp == 0x7fffffff || os > bs || (os == bs && op < bp))) { bs = os; bp = op; }
         }
         if ((tid & 63) == 0) { bsc[tid >> 6] = bs; bpos[tid >> 6] = bp; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int i = 1; i < 16; ++i) {
-                const float os = bsc[i]; const int op = bpos[i];
-                if (op != 0x7fffffff && (bp == 0x7fffffff || os > bs || (os == bs && op < bp))) { bs = os; bp = op; }
-            }
-            if (bs > p.ctrl->best_score) {                                   // strict (cem_mpc.py:58)
-                const int idx = elite[bp];
-                for (int a = 0; a < p.A; ++a) p.ctrl->best[a] = p.actions[(size_t)idx * p.HA + a];   // first step's action
-                p.ctrl->best_score = bs;
-            }
-        }
     }
 
     // ---- moments over the elite set (tf.nn.moments: mean, then mean squared difference) ---------------------
     const float fk = (float)k;
     const float sm = p.smoothing;
-    for (int cb = 0; cb < p.HA; cb += 1024) {
-        const int ncol = (p.HA - cb < 1024) ? p.HA - cb : 1024;
+    for (int cb = 0; cb < HA; cb += 1024) {
+        const int ncol = (HA - cb < 1024) ? HA - cb : 1024;
         int tpc = 1; while (tpc * 2 * ncol <= 1024) tpc *= 2;
         const int part = tid / ncol, col = tid % ncol;
         const bool act = part < tpc;
+        // this thread's elite rows e = part, part + tpc, ...: the first 16 are gathered at once and kept for both phases
+        float av[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int e = part + j * tpc;
+            av[j] = (act && e < k) ? p.actions[(size_t)elite[e] * HA + cb + col] : 0.f;
+        }
         for (int phase = 0; phase < 2; ++phase) {
             float acc = 0.f;
             const float m = phase ? colmean[cb + col] : 0.f;
             if (act) {
-                for (int e = part; e < k; e += tpc) {
-                    const float a = p.actions[(size_t)elite[e] * p.HA + cb + col];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int e = part + j * tpc;
+                    if (e < k) { const float a = av[j]; acc = phase ? acc + (a - m) * (a - m) : acc + a; }
+                }
+                for (int e = part + 16 * tpc; e < k; e += tpc) {
+                    const float a = p.actions[(size_t)elite[e] * HA + cb + col];
                     acc = phase ? acc + (a - m) * (a - m) : acc + a;
                 }
             }
@@ -811,21 +831,34 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
                 else {
                     const float sd = sqrtf(tot / fk);
                     const int ci = cb + col;
-                    p.musig[ci] = sm * p.musig[ci] + (1.0f - sm) * colmean[ci];              // cem_mpc.py:64
-                    p.musig[p.HA + ci] = sm * p.musig[p.HA + ci] + (1.0f - sm) * sd;          // cem_mpc.py:65
+                    const float omu = cb == 0 ? old_mu : p.musig[ci], osg = cb == 0 ? old_sg : p.musig[HA + ci];
+                    const float nsg = sm * osg + (1.0f - sm) * sd;                             // cem_mpc.py:65
+                    p.musig[ci] = sm * omu + (1.0f - sm) * colmean[ci];                        // cem_mpc.py:64
+                    p.musig[HA + ci] = nsg;
+                    newsig[ci] = nsg;
                 }
             }
             __syncthreads();
         }
     }
-    __threadfence_block();
-    __syncthreads();
     if (tid == 0) {
         float ssum = 0.f;
-        for (int i = 0; i < p.HA; ++i) ssum = ssum + p.musig[p.HA + i];
-        const float mean_sigma = ssum / (float)p.HA;
+        for (int i = 0; i < HA; ++i) ssum = ssum + newsig[i];
+        const float mean_sigma = ssum / (float)HA;
         p.ctrl->iters = p.ctrl->iters + 1;
         if (mean_sigma <= p.threshold) p.ctrl->done = 1;                                      // cem_mpc.py:66-67
+    }
+    if (tid == 64) {
+        float bs = bsc[0]; int bp = bpos[0];
+        for (int i = 1; i < 16; ++i) {
+            const float os = bsc[i]; const int op = bpos[i];
+            if (op != 0x7fffffff && (bp == 0x7fffffff || os > bs || (os == bs && op < bp))) { bs = os; bp = op; }
+        }
+        if (bs > p.ctrl->best_score) {                                       // strict (cem_mpc.py:58)
+            const int idx = elite[bp];
+            for (int a = 0; a < p.A; ++a) p.ctrl->best[a] = p.actions[(size_t)idx * HA + a];   // first step's action
+            p.ctrl->best_score = bs;
+        }
     }
 }
 
