@@ -248,7 +248,7 @@ Layout make_layout(const cem_config_t *c, const Dims &d, size_t max_tiles)
     l.kind_sel = take(CEM_NKIND * CEM_U * 4);
     l.tiles = take(max_tiles * sizeof(TileDesc));
     l.eps_out = take(CEM_MAX_ACT * 4);
-    l.stamps = take(max_tiles * 4 * 8 * sizeof(long long));
+    l.stamps = take(std::max<size_t>(max_tiles * 4 * 8, 128) * sizeof(long long));      // [tiles][4][8] rollout stamps; [64..71] select stamps
     l.total = o;
     (void)c;
     return l;
@@ -590,8 +590,19 @@ int enqueue_select(cem_planner *h, int it)
     p.musig = (float *)(ws + l.musig); p.ctrl = (CtrlBlock *)(ws + l.ctrl); p.elite_idx = (int32_t *)(ws + l.elite);
     p.N = d.N; p.k = d.k; p.HA = d.H * d.A; p.A = d.A; p.check_done = 1;
     p.smoothing = h->cfg.smoothing; p.threshold = h->cfg.stddev_threshold;
+    p.stamps = (long long *)(ws + l.stamps) + 64;          // past tile 0's rollout stamps; written by -DCEM_STAMPS builds only
     size_t lds = (size_t)((d.k + 3) & ~3) * 4 + (size_t)2 * d.H * d.A * 4;
-    const bool cache = lds + (size_t)d.N * 4 <= 48 * 1024;          // scores staged in LDS (with the ~7 KB of static arrays: < 64 KB)
+    // scores staged in LDS when they fit: gfx950 has 160 KB per CU and this kernel is the CU's only workgroup; beyond the
+    // default 64 KB per workgroup the runtime has to be asked once (7 KB of the budget are the kernel's static arrays).
+    // N = 16000 (the replicated select of an 8-GPU weak-scaled plan): 71 -> 57 us.
+    static size_t dyn_limit = 0;
+    if (!dyn_limit) {
+        dyn_limit = 48 * 1024;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&cem_select_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                152 * 1024) == hipSuccess) dyn_limit = 152 * 1024;
+        else (void)hipGetLastError();
+    }
+    const bool cache = lds + (size_t)d.N * 4 <= dyn_limit;
     if (cache) lds += (size_t)d.N * 4;
     size_t e0 = 0;
     if (h->timing) { e0 = h->ev_kind.size() * 2; h->ev_kind.push_back({(int)e0, 1}); hipEventRecord(get_event(h, e0), h->stream); }

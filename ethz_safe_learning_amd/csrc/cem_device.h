@@ -662,7 +662,14 @@ struct SelectParams {
     const float *scores; const float *actions; float *musig; CtrlBlock *ctrl; int32_t *elite_idx;
     int32_t N, k, HA, A, check_done;
     float smoothing, threshold;
+    long long *stamps;           // [8] section stamps of -DCEM_STAMPS diagnostic builds
 };
+
+#ifdef CEM_STAMPS
+#define CEM_SEL_STAMP(i) do { if (threadIdx.x == 0 && p.stamps) p.stamps[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CEM_SEL_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ uint32_t cem_f2key(float f)
 {
@@ -706,6 +713,7 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
 
     const int tid = threadIdx.x;
     const int N = p.N, k = p.k, HA = p.HA;
+    CEM_SEL_STAMP(0);
     int32_t *elite = reinterpret_cast<int32_t *>(sel_smem);                 // [k]
     float *colmean = reinterpret_cast<float *>(sel_smem + (size_t)((k + 3) & ~3) * 4);   // [HA]
     float *newsig = colmean + HA;                                           // [HA] smoothed sigma
@@ -727,6 +735,7 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
     const float *S = CACHE ? csc : p.scores;
     if (tid < 256) hist[1][tid] = 0;                  // pass 3 counts into hist[3 & 1]
     __syncthreads();
+    CEM_SEL_STAMP(1);
 
     // ---- radix select of the k-th largest key ----------------------------------------------------------
     uint32_t prefix = 0, mask = 0, need = (uint32_t)k;
@@ -755,6 +764,7 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
         __syncthreads();
         prefix = sh_prefix; need = sh_need; mask |= 0xFFu << (8 * pass);
     }
+    CEM_SEL_STAMP(2);
     const uint32_t T = prefix;          // key of the k-th largest score; `need` ties are taken, lowest index first
 
     // ---- compaction in ascending candidate index (tf.nn.top_k ties -> lower index) -------------------------
@@ -776,6 +786,7 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
     }
     __syncthreads();
 
+    CEM_SEL_STAMP(3);
     // ---- best of elite: max score, first (= lowest index) among exact ties  (cem_mpc.py:57-60) -------------
     // per-wave candidates now; the final combine and the update of best-so-far run on wave 1 at the very end
     {
@@ -792,6 +803,7 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
         if ((tid & 63) == 0) { bsc[tid >> 6] = bs; bpos[tid >> 6] = bp; }
     }
 
+    CEM_SEL_STAMP(4);
     // ---- moments over the elite set (tf.nn.moments: mean, then mean squared difference) ---------------------
     const float fk = (float)k;
     const float sm = p.smoothing;
@@ -816,9 +828,13 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
                     const int e = part + j * tpc;
                     if (e < k) { const float a = av[j]; acc = phase ? acc + (a - m) * (a - m) : acc + a; }
                 }
-                for (int e = part + 16 * tpc; e < k; e += tpc) {
-                    const float a = p.actions[(size_t)elite[e] * HA + cb + col];
-                    acc = phase ? acc + (a - m) * (a - m) : acc + a;
+                for (int e0 = part + 16 * tpc; e0 < k; e0 += 8 * tpc) {      // large k: 8 gathers in flight, same summation order
+                    float b[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const int e = e0 + j * tpc; b[j] = e < k ? p.actions[(size_t)elite[e] * HA + cb + col] : 0.f; }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (e0 + j * tpc < k) { const float a = b[j]; acc = phase ? acc + (a - m) * (a - m) : acc + a; }
                 }
             }
             __syncthreads();
@@ -841,12 +857,14 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
             __syncthreads();
         }
     }
+    CEM_SEL_STAMP(5);
     if (tid == 0) {
         float ssum = 0.f;
         for (int i = 0; i < HA; ++i) ssum = ssum + newsig[i];
         const float mean_sigma = ssum / (float)HA;
         p.ctrl->iters = p.ctrl->iters + 1;
         if (mean_sigma <= p.threshold) p.ctrl->done = 1;                                      // cem_mpc.py:66-67
+        CEM_SEL_STAMP(6);
     }
     if (tid == 64) {
         float bs = bsc[0]; int bp = bpos[0];

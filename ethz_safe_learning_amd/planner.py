@@ -391,7 +391,7 @@ def cached_planner(cfg: PlannerConfig, device='cuda:0') -> CemPlanner:
     pl = _PLANNER_CACHE.pop(key, None)
     if pl is None:
         pl = CemPlanner(cfg, device=device)
-        pl.staged = None                         # (id(model), model.version) whose weights/normaliser are on the device
+        pl.staged = None                         # (model.uid, model.version) whose weights/normaliser are on the device
         while len(_PLANNER_CACHE) >= _PLANNER_CACHE_MAX:
             _PLANNER_CACHE.pop(next(iter(_PLANNER_CACHE))).close()
     _PLANNER_CACHE[key] = pl                     # most recently used last

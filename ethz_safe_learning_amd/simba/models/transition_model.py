@@ -7,7 +7,11 @@ import numpy as np
 
 from ..infrastructure.common import standardize_name
 from .model import BaseModel
+import itertools
+
 from .mlp_ensemble import MlpEnsemble
+
+_MODEL_UIDS = itertools.count(1)
 
 _MODELS = {'MlpEnsemble': MlpEnsemble}
 
@@ -26,6 +30,7 @@ class TransitionModel(BaseModel):
         self.inputs_min = np.concatenate([observation_space.low, action_space.low]).astype(np.float32)    # :28
         self.inputs_max = np.concatenate([observation_space.high, action_space.high]).astype(np.float32)  # :29
         self._stats_version = 0
+        self.uid = next(_MODEL_UIDS)             # process-unique (id() is reused after garbage collection): keys staged weights
         self._planner = None
         self._planner_version = None
 

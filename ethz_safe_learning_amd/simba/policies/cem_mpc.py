@@ -59,7 +59,7 @@ class CemMpc(MpcPolicy):
         self._sync_model()
 
     def _sync_model(self):
-        tag = (id(self.model), self.model.version)
+        tag = (self.model.uid, self.model.version)            # uid, not id(): ids are reused after garbage collection
         if self._planner.staged != tag:
             self._planner.set_weights(self.model.model.get_weights())
             self._planner.set_normaliser(self.model.inputs_min, self.model.inputs_max)

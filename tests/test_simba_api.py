@@ -74,6 +74,20 @@ def test_transition_model_statistics_and_scale():
             model.fit(data, data[:, :60])
 
 
+def test_model_uid_is_unique_per_instance():
+    """The planner-handle cache tags staged weights with (model.uid, model.version).  id() is recycled after garbage
+    collection, so two models that never coexist can share an id — a uid never repeats."""
+    import gc
+    uids, ids = set(), set()
+    for seed in range(6):
+        env, model, _ = make_agent_parts('cem_mpc', seed=seed)
+        assert model.uid not in uids
+        uids.add(model.uid); ids.add(id(model))
+        del env, model, _
+        gc.collect()
+    assert len(uids) == 6
+
+
 def test_scorer_config_variants():
     table = dict(goal_dist=slice(0, 1), hazards_lidar=slice(1, 6), vases_lidar=slice(6, 11))
     s = SafetyGymStateScorer(dict(task='goal', observe_goal_lidar=False, observe_goal_dist=True, goal_size=0.3, lidar_max_dist=4,
@@ -127,6 +141,28 @@ def test_generate_action_at_shipped_config_matches_oracle(policy_name):
     assert pol.last_iterations == rit, 'early stop (stddev_threshold 0.25) must trigger at the same iteration'
     assert abs(s - rs) <= 1e-4
     np.testing.assert_allclose(a, ra, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_same_shape_policies_restage_their_own_model():
+    """Two policies of one shape share a cached planner handle; each must plan with ITS model's weights, also when the
+    first model has been garbage collected (its id() may be handed to the second)."""
+    import gc
+    state = np.zeros(60, np.float64); state[3:19] = 0.5; state[22:38] = 0.6
+    rng = np.random.default_rng(0)
+    pp = POLICIES_YAML['cem_mpc']
+    ea = rng.standard_normal((pp['iterations'], pp['n_samples'], pp['horizon'], 2)).astype(np.float32)
+    scores = []
+    for seed in (11, 12, 11):
+        env, model, pol = make_agent_parts('cem_mpc', seed=seed)
+        trained_like(model, np.random.default_rng(seed))
+        I, N, H = pol.iterations, pol.n_samples, pol.horizon
+        a, s = pol.do_generate_action(state, eps_act=ea, eps_model=np.zeros((I, H, pol.particles * N, 60), np.float32),
+                                      eps_out=np.zeros(2, np.float32))
+        scores.append(float(s))
+        del env, model, pol
+        gc.collect()
+    assert scores[0] == scores[2] and scores[0] != scores[1], scores
 
 
 @pytest.mark.gpu
