@@ -321,7 +321,7 @@ def test_b2_full_size_properties():
         _, c2 = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, world_size=2, rank=r)
         halves.append(scores_of(hp.make_planner(pb, c2)))
     np.testing.assert_array_equal(np.concatenate(halves), s_a)
-    for rc in (1, 2, 4):
+    for rc in (1, 2, 3, 4):                         # every tile size of the obs+act <= 64 kernel family, bit for bit
         _, c3 = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, chunks_per_tile=rc)
         np.testing.assert_array_equal(scores_of(hp.make_planner(pb, c3)), s_a)
     # a bounded oracle check at full width: the first 64 candidates of iteration 0 on the dumped noise
@@ -413,6 +413,9 @@ def test_large_baseline_configs_properties(name, O, A, K, N, H):
         _, c2 = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, world_size=2, rank=r)
         halves.append(scores_of(hp.make_planner(pb, c2)))
     np.testing.assert_array_equal(np.concatenate(halves), s1)
+    for rc in ((1, 2, 3, 4) if name == 'B4' else (2,)):   # every tile size of the obs+act > 64 kernel family (B4), bit for bit
+        _, c3 = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, chunks_per_tile=rc)
+        np.testing.assert_array_equal(scores_of(hp.make_planner(pb, c3)), s1)
     # bounded oracle check: the first 32 candidates on the dumped noise of iteration 0
     ea, em, eo = pl.fill_noise(seed=5, call=2)
     sub = 32
