@@ -393,7 +393,9 @@ def cached_planner(cfg: PlannerConfig, device='cuda:0') -> CemPlanner:
         pl = CemPlanner(cfg, device=device)
         pl.staged = None                         # (model.uid, model.version) whose weights/normaliser are on the device
         while len(_PLANNER_CACHE) >= _PLANNER_CACHE_MAX:
-            _PLANNER_CACHE.pop(next(iter(_PLANNER_CACHE))).close()
+            # least recently used entry: only the cache's reference goes; a policy still holding the handle keeps it alive
+            # (CemPlanner.__del__ destroys it with its last reference)
+            _PLANNER_CACHE.pop(next(iter(_PLANNER_CACHE)))
     _PLANNER_CACHE[key] = pl                     # most recently used last
     return pl
 

@@ -53,7 +53,7 @@ class CemMpc(MpcPolicy):
             use_graph=self.use_graph, **self._extra_config())
 
     def build(self):
-        if self._planner is None:
+        if self._planner is None or self._planner.h is None:      # never built, or closed by its owner
             # one handle per distinct shape, shared by every policy object of that shape (tune_cem_policy.py:109-115)
             self._planner = cached_planner(self.planner_config(), device=self.device)
         self._sync_model()
@@ -67,18 +67,14 @@ class CemMpc(MpcPolicy):
 
     # ---- the plugin boundary ------------------------------------------------------------------------------------
     def generate_action(self, state):
-        if self._planner is None:
-            self.build()
-        self._sync_model()
+        self.build()                                   # cached handle + weights of the current model version
         action, score, iters = self._planner.plan(np.asarray(state, np.float32), seed=self.seed)
         self.last_score, self.last_iterations = score, iters
         return action
 
     def do_generate_action(self, state, eps_act=None, eps_model=None, eps_out=None):
         """(action, best_score) like cem_mpc.py:35-68; explicit noise tensors replace TF's stateful RNG."""
-        if self._planner is None:
-            self.build()
-        self._sync_model()
+        self.build()
         action, score, iters = self._planner.plan(np.asarray(state, np.float32), seed=self.seed, eps_act=eps_act,
                                                   eps_model=eps_model, eps_out=eps_out)
         self.last_iterations = iters
