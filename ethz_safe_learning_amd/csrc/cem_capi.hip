@@ -593,13 +593,13 @@ int enqueue_select(cem_planner *h, int it)
     p.stamps = (long long *)(ws + l.stamps) + 64;          // past tile 0's rollout stamps; written by -DCEM_STAMPS builds only
     size_t lds = (size_t)((d.k + 3) & ~3) * 4 + (size_t)2 * d.H * d.A * 4;
     // scores staged in LDS when they fit: gfx950 has 160 KB per CU and this kernel is the CU's only workgroup; beyond the
-    // default 64 KB per workgroup the runtime has to be asked once (7 KB of the budget are the kernel's static arrays).
+    // default 64 KB per workgroup the runtime has to be asked once (19 KB of the budget are the kernel's static arrays).
     // N = 16000 (the replicated select of an 8-GPU weak-scaled plan): 71 -> 57 us.
     static size_t dyn_limit = 0;
     if (!dyn_limit) {
         dyn_limit = 48 * 1024;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&cem_select_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                152 * 1024) == hipSuccess) dyn_limit = 152 * 1024;
+                                140 * 1024) == hipSuccess) dyn_limit = 140 * 1024;
         else (void)hipGetLastError();
     }
     const bool cache = lds + (size_t)d.N * 4 <= dyn_limit;

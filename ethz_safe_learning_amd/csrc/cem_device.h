@@ -678,6 +678,29 @@ __device__ __forceinline__ uint32_t cem_f2key(float f)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// Histogram add for a whole wave when few bins are hot (the first counted radix pass: sign + exponent bits): LDS atomics
+// on one address serialise, so up to four rounds of "leader's digit -> one add of the group size", plain adds for the rest.
+__device__ __forceinline__ void cem_hist_add_clustered(uint32_t *hist, bool match, const uint32_t digit)
+{
+    const int lane = threadIdx.x & 63;
+    uint64_t rem = __builtin_amdgcn_ballot_w64(match);
+#pragma unroll 1
+    for (int round = 0; round < 4 && rem; ++round) {
+        const int leader = __builtin_ctzll(rem);
+        const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)digit, leader);
+        const uint64_t same = __builtin_amdgcn_ballot_w64(match && digit == d);
+        if (lane == leader) atomicAdd(&hist[d], (uint32_t)__builtin_popcountll(same));
+        rem &= ~same;
+        if ((same >> lane) & 1ull) match = false;
+    }
+    if (match) atomicAdd(&hist[digit], 1u);
+}
+
+__device__ __forceinline__ float cem_key2f(const uint32_t key)       // inverse of cem_f2key (a NaN comes back as a NaN)
+{
+    return __uint_as_float((key & 0x80000000u) ? (key ^ 0x80000000u) : ~key);
+}
+
 // exclusive scans of two values per thread over a 1024-thread block (one barrier): pa, pb = sums over lower thread ids
 __device__ __forceinline__ void cem_block_excl_scan2(const uint32_t a, const uint32_t b, uint32_t (*wsum)[16], uint32_t &pa, uint32_t &pb)
 {
@@ -706,7 +729,7 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
     __shared__ __attribute__((aligned(16))) uint32_t hist[2][256];
     __shared__ uint32_t wsum[2][16];
     __shared__ uint32_t sh_prefix, sh_need;
-    __shared__ float red[1024];
+    __shared__ __attribute__((aligned(16))) float red[4096];   // per-thread partial sums (float4 in the wide moments path)
     __shared__ float bsc[16];
     __shared__ int bpos[16];
     if (p.check_done && p.ctrl->done) return;
@@ -717,34 +740,68 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
     int32_t *elite = reinterpret_cast<int32_t *>(sel_smem);                 // [k]
     float *colmean = reinterpret_cast<float *>(sel_smem + (size_t)((k + 3) & ~3) * 4);   // [HA]
     float *newsig = colmean + HA;                                           // [HA] smoothed sigma
-    float *csc = newsig + HA;                                               // [N] scores (CACHE)
+    uint32_t *ckey = reinterpret_cast<uint32_t *>(newsig + HA);             // [N] order-preserving keys of the scores (CACHE)
 
     // old mu / sigma of the columns this thread will finish (first column block): requested now, needed at the very end
     float old_mu = 0.f, old_sg = 0.f;
     if (tid < HA) { old_mu = p.musig[tid]; old_sg = p.musig[HA + tid]; }
 
+    // stage the keys; their block-wide min / max tell which leading bytes every key shares (scores of one iteration
+    // usually share sign and exponent): those radix passes have nothing to count
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
     if (CACHE) {
         for (int i0 = 0; i0 < N; i0 += 4096) {
             float v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) { const int i = i0 + j * 1024 + tid; if (i < N) v[j] = p.scores[i]; }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const int i = i0 + j * 1024 + tid; if (i < N) csc[i] = v[j]; }
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + j * 1024 + tid;
+                if (i < N) { const uint32_t key = cem_f2key(v[j]); ckey[i] = key; kmin = key < kmin ? key : kmin; kmax = key > kmax ? key : kmax; }
+            }
         }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t a = (uint32_t)__shfl_xor((int)kmin, d), b = (uint32_t)__shfl_xor((int)kmax, d);
+            kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
+        }
+        if ((tid & 63) == 0) { wsum[0][tid >> 6] = kmin; wsum[1][tid >> 6] = kmax; }
     }
-    const float *S = CACHE ? csc : p.scores;
+    auto K = [&](const int i) { return CACHE ? ckey[i] : cem_f2key(p.scores[i]); };
     if (tid < 256) hist[1][tid] = 0;                  // pass 3 counts into hist[3 & 1]
     __syncthreads();
+    uint32_t kdiff = 0xFFFFFFFFu;
+    if (CACHE) {
+        for (int i = 0; i < 16; ++i) { kmin = wsum[0][i] < kmin ? wsum[0][i] : kmin; kmax = wsum[1][i] > kmax ? wsum[1][i] : kmax; }
+        kdiff = kmin ^ kmax;
+        __syncthreads();                              // wsum is reused by the compaction scan
+    }
     CEM_SEL_STAMP(1);
 
     // ---- radix select of the k-th largest key ----------------------------------------------------------
     uint32_t prefix = 0, mask = 0, need = (uint32_t)k;
+    bool leading = true;
     for (int pass = 3; pass >= 0; --pass) {
         const int hb = pass & 1;
-        for (int i = tid; i < N; i += 1024) {
-            const uint32_t key = cem_f2key(S[i]);
-            if ((key & mask) == prefix) atomicAdd(&hist[hb][(key >> (8 * pass)) & 255u], 1u);
+        if (leading && ((kdiff >> (8 * pass)) & 255u) == 0u) {             // every key has this byte (workgroup-uniform test)
+            prefix |= kmin & (0xFFu << (8 * pass)); mask |= 0xFFu << (8 * pass);
+            if (tid < 256) hist[hb ^ 1][tid] = 0;
+            __syncthreads();
+            continue;
         }
+        if (leading) {                                 // first counted pass: few hot bins; whole waves enter (wave-level add)
+            for (int i0 = 0; i0 < N; i0 += 1024) {
+                const int i = i0 + tid;
+                const uint32_t key = i < N ? K(i) : 0u;
+                cem_hist_add_clustered(hist[hb], i < N && (key & mask) == prefix, (key >> (8 * pass)) & 255u);
+            }
+        } else {
+            for (int i = tid; i < N; i += 1024) {
+                const uint32_t key = K(i);
+                if ((key & mask) == prefix) atomicAdd(&hist[hb][(key >> (8 * pass)) & 255u], 1u);
+            }
+        }
+        leading = false;
         if (tid < 256) hist[hb ^ 1][tid] = 0;         // the next pass's histogram
         __syncthreads();
         // ge[b] = #keys in bins >= b; the one bin with ge[b] >= need > ge[b+1] is the next byte of the k-th largest key.
@@ -771,14 +828,14 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
     const int C = (N + 1023) / 1024;
     const int beg = tid * C, end = (beg + C < N) ? beg + C : N;
     uint32_t ngt = 0, neq = 0;
-    for (int i = beg; i < end; ++i) { const uint32_t key = cem_f2key(S[i]); ngt += key > T; neq += key == T; }
+    for (int i = beg; i < end; ++i) { const uint32_t key = K(i); ngt += key > T; neq += key == T; }
     uint32_t pre_gt, pre_eq;
     cem_block_excl_scan2(ngt, neq, wsum, pre_gt, pre_eq);
     {
         uint32_t eqr = pre_eq;
         uint32_t pos = pre_gt + (pre_eq < need ? pre_eq : need);
         for (int i = beg; i < end; ++i) {
-            const uint32_t key = cem_f2key(S[i]);
+            const uint32_t key = K(i);
             bool take = key > T;
             if (key == T) { take = eqr < need; ++eqr; }
             if (take) { elite[pos] = i; p.elite_idx[pos] = i; ++pos; }
@@ -792,7 +849,7 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
     {
         float bs = -__builtin_inff(); int bp = 0x7fffffff;
         for (int e = tid; e < k; e += 1024) {
-            const float sc = S[elite[e]];
+            const float sc = CACHE ? cem_key2f(ckey[elite[e]]) : p.scores[elite[e]];
             if (bp == 0x7fffffff || sc > bs) { bs = sc; bp = e; }
         }
 #pragma unroll
@@ -807,6 +864,69 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
     // ---- moments over the elite set (tf.nn.moments: mean, then mean squared difference) ---------------------
     const float fk = (float)k;
     const float sm = p.smoothing;
+    // Wide path for large elite sets (the replicated select of a multi-GPU plan): a thread gathers whole float4s of an elite's
+    // action row, i.e. a quarter of the address arithmetic and load instructions per element — this kernel is issue-bound
+    // on its one CU.  Partial sums still add up in a fixed order (elite index ascending within a part, parts ascending).
+    {
+        int tpc1 = 1; { const int nc = HA < 1024 ? HA : 1024; while (tpc1 * 2 * nc <= 1024) tpc1 *= 2; }
+        if ((HA & 3) == 0 && HA <= 4096 && k > 16 * tpc1) {
+            const int ncol4 = HA >> 2;
+            int tpc = 1; while (tpc * 2 * ncol4 <= 1024) tpc *= 2;
+            const int part = tid / ncol4, c4 = tid % ncol4;
+            const bool act = part < tpc;
+            f4 *red4 = reinterpret_cast<f4 *>(red);
+            const f4 *act4 = reinterpret_cast<const f4 *>(p.actions);
+            const f4 zero4 = (f4){0.f, 0.f, 0.f, 0.f};
+            f4 av[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = part + j * tpc;
+                av[j] = (act && e < k) ? act4[(size_t)elite[e] * ncol4 + c4] : zero4;
+            }
+            f4 mean4 = zero4;
+            for (int phase = 0; phase < 2; ++phase) {
+                f4 acc = zero4;
+                if (act) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (part + j * tpc < k) { const f4 a = av[j]; acc = phase ? acc + (a - mean4) * (a - mean4) : acc + a; }
+                    for (int e0 = part + 8 * tpc; e0 < k; e0 += 8 * tpc) {
+                        f4 b[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { const int e = e0 + j * tpc; b[j] = e < k ? act4[(size_t)elite[e] * ncol4 + c4] : zero4; }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (e0 + j * tpc < k) { const f4 a = b[j]; acc = phase ? acc + (a - mean4) * (a - mean4) : acc + a; }
+                    }
+                }
+                __syncthreads();
+                red4[tid] = acc;
+                __syncthreads();
+                if (part == 0) {
+                    f4 tot = zero4;
+                    for (int pp = 0; pp < tpc; ++pp) tot = tot + red4[pp * ncol4 + c4];
+                    if (!phase) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) colmean[4 * c4 + r] = tot[r] / fk;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float sd = sqrtf(tot[r] / fk);
+                            const int ci = 4 * c4 + r;
+                            const float nsg = sm * p.musig[HA + ci] + (1.0f - sm) * sd;                // cem_mpc.py:65
+                            p.musig[ci] = sm * p.musig[ci] + (1.0f - sm) * colmean[ci];                // cem_mpc.py:64
+                            p.musig[HA + ci] = nsg;
+                            newsig[ci] = nsg;
+                        }
+                    }
+                }
+                __syncthreads();
+                if (!phase && act) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mean4[r] = colmean[4 * c4 + r];
+                }
+            }
+        } else
     for (int cb = 0; cb < HA; cb += 1024) {
         const int ncol = (HA - cb < 1024) ? HA - cb : 1024;
         int tpc = 1; while (tpc * 2 * ncol <= 1024) tpc *= 2;
@@ -856,6 +976,7 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
             }
             __syncthreads();
         }
+    }
     }
     CEM_SEL_STAMP(5);
     if (tid == 0) {

@@ -188,6 +188,34 @@ def test_select_edge_cases(case):
     np.testing.assert_allclose(ms[1], np.sqrt(var), rtol=1e-4, atol=1e-6)
 
 
+def test_select_wide_moments_path_matches_oracle():
+    """The select kernel of a weak-scaled 8-GPU plan: N = 16000 candidates, k = 1600 elites, H*A = 60 — large k takes the
+    float4 gather path of the moments.  Elite set exact on the GPU's own scores; mu / sigma / best action vs the oracle."""
+    torch = _torch()
+    pb = hp.make_problem(seed=43)
+    N, H, P, E, k = 16000, 30, 5, 5, 1600
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=2, smoothing=0.1)
+    pl = hp.make_planner(pb, pcfg)
+    pl.plan_begin(pb['state'], seed=21, call=0)
+    pl.plan_rollout(0)
+    torch.cuda.synchronize()
+    scores = pl.scores_local().cpu().numpy().copy()
+    actions = pl.actions().cpu().numpy().copy()
+    ms0 = pl.mu_sigma().cpu().numpy().copy()
+    pl.plan_select(0)
+    torch.cuda.synchronize()
+    elite = np.sort(pl.elite_idx().cpu().numpy())
+    ms1 = pl.mu_sigma().cpu().numpy()
+    mu, sigma, best, best_score, ref_elite, stop = o.select_and_refit(scores, actions, ms0[0], ms0[1], np.zeros(2, np.float32),
+                                                                      np.float32(-np.inf), ocfg)
+    np.testing.assert_array_equal(elite, ref_elite)
+    np.testing.assert_allclose(ms1[0], mu, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ms1[1], sigma, rtol=1e-5, atol=1e-6)
+    a, sc, it = pl.plan_end(eps_out=np.zeros(2, np.float32))
+    np.testing.assert_array_equal(a, best)
+    assert sc == best_score
+
+
 # ------------------------------------------------------------------------------------------------- whole plan
 @pytest.mark.parametrize('variant', ['cem', 'safe'])
 def test_full_plan_matches_oracle(variant):
