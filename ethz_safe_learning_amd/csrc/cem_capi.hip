@@ -165,9 +165,9 @@ void build_plan_tiles(const Dims &d, int rc, std::vector<Tile6> &out)
 // Cost of one 16-row chunk for the whole horizon, in units of the measured B-config sweeps (ms at H = 30, MI355X, round 1:
 // profiles/r01_sweep_chunks.txt): `solo` with one workgroup on the CU, `shared` with two or more.  Larger tiles re-use each
 // streamed weight group for more rows (less L2 traffic); smaller tiles pack the CUs more evenly and co-reside more easily.
-static const double kChunkSolo[2][4] = {{0.192, 0.168, 0.159, 0.157}, {1.25, 1.056, 1.02, 1.006}};
-static const double kChunkShared[2][4] = {{0.153, 0.148, 0.1445, 0.1445}, {1.00, 0.97, 0.94, 0.93}};
-static const int kResidentStatic[2][4] = {{3, 2, 2, 2}, {2, 1, 1, 1}};     // from the kernels' VGPR counts (155/181/221/249, 229/275/334/408)
+static const double kChunkSolo[2][4] = {{0.192, 0.168, 0.159, 0.157}, {1.25, 1.056, 1.010, 0.999}};
+static const double kChunkShared[2][4] = {{0.153, 0.148, 0.1445, 0.1445}, {1.00, 0.949, 0.93, 0.92}};
+static const int kResidentStatic[2][4] = {{3, 2, 2, 2}, {2, 2, 1, 1}};     // from the kernels' VGPR counts (155/181/221/249, 206/240/274/335)
 
 template <int RC, int NFW>
 int query_resident()

@@ -212,7 +212,12 @@ struct WRing {
 // One dense stage for this wave: acc{0,1}[c] += W^T-groups . hB.  hB[0..NOWN-1] (the wave's own blocks) are already
 // in registers; if EXCHANGE, the barrier that publishes the other waves' blocks and the LDS reads of hB[NOWN..KF-1]
 // are issued after the first group's MFMAs.  L0IN selects the block permutation (layer-0 input vs hidden input).
-template <int RC, int KF, int NOWN, bool L0IN, bool EXCHANGE>
+// XMODE 1: barrier after the first group, then just-in-time LDS reads of the other waves' blocks; 2: the same reads without
+// the barrier (the blocks were published and waited for by an earlier stage on the same input and are re-read rather than
+// kept: eight blocks held in registers across two stages cost the obs+act > 64 kernels their second resident workgroup).
+#define CEM_X_EXCHANGE 1
+#define CEM_X_REREAD 2
+template <int RC, int KF, int NOWN, bool L0IN, int XMODE>
 __device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], f4 (&hB)[CEM_NG][RC], WRing &wq,
                                                const char *smem, const int xr, const int lane, const int w)
 {
@@ -224,10 +229,10 @@ __device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], f
         // pin the prefetch here: unpinned, the machine scheduler sinks the load to just before its use and every
         // group of MFMAs eats a full L2 round trip
         __builtin_amdgcn_sched_barrier(0);
-        if (EXCHANGE && P >= 1) {
+        if (XMODE != 0 && P >= 1) {
             // the other waves' blocks are read just in time, CEM_LDS_AHEAD groups before their MFMAs: all of them at once
             // is 24*RC live registers from group 1 on, which at RC = 3 pushes the kernel over the 256 architectural VGPRs
-            if (P == 1) __syncthreads();                  // every wave's blocks of the previous stage are in LDS
+            if (P == 1 && XMODE == CEM_X_EXCHANGE) __syncthreads();   // every wave's blocks of the previous stage are in LDS
 #pragma unroll
             for (int Q = NOWN; Q < KF; ++Q) {
                 const bool now = (P == 1) ? (Q <= 1 + CEM_LDS_AHEAD) : (Q == P + CEM_LDS_AHEAD);
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
                 for (int c = 0; c < RC; ++c) { acc0[c] = nb0; acc1[c] = nb1; }
                 CEM_NEXT_BIAS(p.L > 1 ? 1 : 0);
                 // stage input = previous stage's output buffer = xw ^ XB (the previous stage toggled xw after writing)
-                cem_mfma_stage<RC, 4 * NFW, NFW, true, true>(acc0, acc1, hB, wq, smem, xw ^ XB, lane, w);
+                cem_mfma_stage<RC, 4 * NFW, NFW, true, CEM_X_EXCHANGE>(acc0, acc1, hB, wq, smem, xw ^ XB, lane, w);
                 CEM_BOOKKEEP(t - 1);                      // the barrier inside the stage published step t-1's scorer terms
                 CEM_RELU_PUBLISH();
                 CEM_STAMP(0);
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
 #pragma unroll
                 for (int c = 0; c < RC; ++c) { acc0[c] = nb0; acc1[c] = nb1; }
                 CEM_NEXT_BIAS(l + 1 < p.L ? l + 1 : 0);
-                cem_mfma_stage<RC, CEM_NG, 2, false, true>(acc0, acc1, hB, wq, smem, xw ^ XB, lane, w);
+                cem_mfma_stage<RC, CEM_NG, 2, false, CEM_X_EXCHANGE>(acc0, acc1, hB, wq, smem, xw ^ XB, lane, w);
                 CEM_RELU_PUBLISH();
                 CEM_STAMP(1);
             }
@@ -454,8 +459,8 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
             if (t >= 0) {
                 // the first heads stage also performs the exchange of the last hidden layer's output
                 if (Fo < p.KB_obs) {                                                           // wave-uniform
-                    if (i == 0) cem_mfma_stage<RC, CEM_NG, 2, false, true>(accm, accv, hB, wq, smem, xw ^ XB, lane, w);
-                    else cem_mfma_stage<RC, CEM_NG, 2, false, false>(accm, accv, hB, wq, smem, xw ^ XB, lane, w);
+                    if (i == 0) cem_mfma_stage<RC, CEM_NG, 2, false, CEM_X_EXCHANGE>(accm, accv, hB, wq, smem, xw ^ XB, lane, w);
+                    else cem_mfma_stage<RC, CEM_NG, 2, false, CEM_X_REREAD>(accm, accv, hB, wq, smem, xw ^ XB, lane, w);
                 } else if (i == 0) {
                     __syncthreads();                      // keep the barrier count of waves without observation features
                 }
