@@ -1,7 +1,9 @@
 """Experiment configuration: built-in defaults for policies / models / agents (the hyper-parameters the reference ships
 in config/policies.yaml, config/models.yaml, config/agents.yaml) overridden recursively by an experiment YAML
 (reference config/config.py:5-39).  ``load_config_or_die(config_dir, config_basename)`` keeps the reference's signature;
-if the directory also holds models.yaml / policies.yaml / agents.yaml they replace the built-in defaults."""
+if the directory also holds models.yaml / policies.yaml / agents.yaml they replace the built-in defaults, and the
+reference's experiment names (experiment, experiment_no_sample, experiment_unaware, debug, tune_policy) resolve to built-in
+presets when no file of that name exists."""
 import copy
 import os
 
@@ -26,6 +28,26 @@ DEFAULTS = {
 }
 
 
+def _options(log_frequency, eval_steps, eval_len, train_iterations, fps=60, **extra):
+    o = dict(trainer_options=dict(video_log_frequency=-1, log_frequency=log_frequency, max_video_length=1000,
+                                  eval_interaction_steps=eval_steps, eval_episode_length=eval_len,
+                                  training_logger_params=dict(fps=fps)),
+             train_iterations=train_iterations, agent='mbrl_agent', environment='MbrlSafexp-PointSimpleGoal1-v0')
+    o.update(extra)
+    return o
+
+
+# The experiment set the reference ships (config/experiment*.yaml, debug.yaml, tune_policy.yaml; scripts/run_experiments.sh
+# selects them with --config_basename), as overrides of DEFAULTS.  A YAML of that name in --config_dir takes precedence.
+PRESETS = {
+    'experiment': dict(options=_options(7, 4000, 1000, 125)),
+    'experiment_no_sample': dict(options=_options(7, 4000, 1000, 125), agents=dict(mbrl_agent=dict(sampling_propagation=False))),
+    'experiment_unaware': dict(options=_options(7, 4000, 1000, 125), agents=dict(mbrl_agent=dict(policy='cem_mpc'))),
+    'debug': dict(options=_options(1, 25, 25, 100)),
+    'tune_policy': dict(options=_options(-1, 25, 25, 60, fps=28, seed=1), models=dict(mlp_ensemble=dict(ensemble_size=5))),
+}
+
+
 def overwrite_default_values(update_from, update_to):
     for key, value in update_from.items():
         if isinstance(value, dict) and isinstance(update_to.get(key), dict):
@@ -42,8 +64,18 @@ def load_config_or_die(config_dir, config_basename):
         if os.path.exists(path):
             with open(path, 'r') as fh:
                 config.update(yaml.safe_load(fh))
-    with open(os.path.join(config_dir, config_basename), 'r') as fh:
-        overwrite_default_values(yaml.safe_load(fh) or {}, config)
+    path = os.path.join(config_dir, config_basename)
+    if not os.path.exists(path) and os.path.exists(path + '.yaml'):
+        path += '.yaml'
+    if os.path.exists(path):
+        with open(path, 'r') as fh:
+            overwrite_default_values(yaml.safe_load(fh) or {}, config)
+    else:
+        preset = os.path.splitext(os.path.basename(config_basename))[0]
+        if preset not in PRESETS:
+            raise FileNotFoundError('no experiment file %s and no built-in experiment %r (built-ins: %s)'
+                                    % (path, preset, ', '.join(sorted(PRESETS))))
+        overwrite_default_values(copy.deepcopy(PRESETS[preset]), config)
     return config
 
 

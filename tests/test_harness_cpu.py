@@ -87,3 +87,22 @@ def test_action_repeat_rollout_and_goal_met_cut():
     assert traj['action'].shape[1] == 2 and all(c == (60,) for c in calls)
     trajs, n = agent.sample_trajectories(env, Policy(env.action_space), 200, 120)
     assert n >= 200 and len(trajs) == 2
+
+
+def test_reference_experiment_names_resolve_to_presets(tmp_path):
+    """scripts/run_experiments.sh of the reference selects experiment / experiment_no_sample / experiment_unaware by
+    --config_basename; here they are built-in overrides of the shipped defaults (a YAML of that name would win)."""
+    from ethz_safe_learning_amd.config.config import load_config_or_die
+    base = load_config_or_die(str(tmp_path), 'experiment.yaml')
+    assert base['options']['train_iterations'] == 125 and base['agents']['mbrl_agent']['policy'] == 'safe_cem_mpc'
+    assert base['agents']['mbrl_agent']['sampling_propagation'] is True
+    assert load_config_or_die(str(tmp_path), 'experiment_no_sample')['agents']['mbrl_agent']['sampling_propagation'] is False
+    assert load_config_or_die(str(tmp_path), 'experiment_unaware.yaml')['agents']['mbrl_agent']['policy'] == 'cem_mpc'
+    tune = load_config_or_die(str(tmp_path), 'tune_policy.yaml')
+    assert tune['models']['mlp_ensemble']['ensemble_size'] == 5 and tune['options']['seed'] == 1
+    assert tune['models']['mlp_ensemble']['training_steps'] == 5000                      # untouched defaults survive the merge
+    (tmp_path / 'debug.yaml').write_text('options:\n  train_iterations: 3\n')
+    assert load_config_or_die(str(tmp_path), 'debug.yaml')['options']['train_iterations'] == 3   # a file wins over the preset
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        load_config_or_die(str(tmp_path), 'nonexistent.yaml')
