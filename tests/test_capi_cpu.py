@@ -156,3 +156,22 @@ def test_xcd_order_groups_members(built_lib):
     for x in range(8):
         members = set(tiles[x::8, 2].tolist())
         assert len(members) <= 3
+
+
+# ---- property-based checks of the host logic (hypothesis) ---------------------------------------------------------------
+from hypothesis import given, settings, strategies as st
+
+
+@settings(max_examples=60, deadline=None)
+@given(E=st.integers(1, 6), ppm=st.integers(1, 3), nmul=st.integers(1, 40), world=st.sampled_from([1, 2, 4]), chunks=st.integers(0, 4),
+       obs=st.sampled_from([40, 60, 100]), data=st.data())
+def test_tiles_partition_property(built_lib, E, ppm, nmul, world, chunks, obs, data):
+    """For arbitrary (E, P, N, world, rank, tile size): tiles partition the rank's rows exactly once, never cross a member
+    boundary (member(r) = r // (B/E), mlp_ensemble.py:123-126), and carry the global noise row / action indices."""
+    P, N = E * ppm, nmul * world                       # P a multiple of E keeps P*N divisible by E (tf.split)
+    rank = data.draw(st.integers(0, world - 1))
+    cfg = _cfg(obs_dim=obs, act_dim=2, ensemble_size=E, particles=P, n_samples=N, n_elite=max(1, N // 10), world_size=world,
+               rank=rank, chunks_per_tile=chunks)
+    rc, tiles = plan_tiles(cfg)
+    assert 1 <= rc <= 4 and (chunks == 0 or rc == chunks)
+    _check_tiles(cfg, rc, tiles)

@@ -1,0 +1,23 @@
+"""examples/capi_minimal.py: the C ABI driven by bare ctypes (the binding INTEGRATION.md section 2 describes) runs and is
+deterministic, independently of this repo's planner.py wrapper."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_capi_minimal_example_runs_and_is_deterministic():
+    sys.path.insert(0, os.path.join(ROOT, 'examples'))
+    import capi_minimal
+    a1, s1, it1 = capi_minimal.main(seed=3)
+    a2, s2, it2 = capi_minimal.main(seed=3)
+    assert a1.shape == (2,) and np.isfinite(a1).all() and np.all(np.abs(a1) <= 1.0 + 0.1)
+    assert it1 == 4 and np.isfinite(s1)
+    np.testing.assert_array_equal(a1, a2)
+    assert s1 == s2 and it1 == it2
+    a3, s3, _ = capi_minimal.main(seed=4)
+    assert not np.array_equal(a1, a3)
