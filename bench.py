@@ -76,7 +76,10 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if G > 1:
+    # CEM_BENCH_FORCE_DIST=1: run the multi-rank leg (process group, stepwise plan with the score all-gather, max-over-ranks
+    # timing) with however many ranks there are, even one — the only way to rehearse that leg on a one-GPU box
+    distributed = G > 1 or os.environ.get('CEM_BENCH_FORCE_DIST') == '1'
+    if distributed:
         assert world == G, 'launch with torch.distributed.run --nproc-per-node %d' % G
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -84,7 +87,7 @@ def main():
     else:
         dist = None
         torch.cuda.set_device(0)
-    dev = 'cuda:%d' % (local_rank if G > 1 else 0)
+    dev = 'cuda:%d' % (local_rank if distributed else 0)
 
     obs, act, K, H, I = 60, 2, 5, 30, 5
     N = args.n_per_gpu * G
@@ -93,14 +96,14 @@ def main():
     cfg = PlannerConfig(obs_dim=obs, act_dim=act, ensemble_size=K, particles=K, n_samples=N, horizon=H, n_elite=k,
                         iterations=I, scorer=pb['scorer'], act_low=pb['low'], act_high=pb['high'], stddev_threshold=-1.0,
                         noise_stddev=1e-3, variant='cem', world_size=G, rank=rank, chunks_per_tile=args.chunks,
-                        use_graph=(G == 1 and not args.no_graph))
+                        use_graph=(not distributed and not args.no_graph))
     pl = CemPlanner(cfg, device=dev)
     pl.set_weights(pb['weights'])
     pl.set_normaliser(pb['inputs_min'], pb['inputs_max'])
-    drv = ShardedCemDriver(pl, I, world_size=G)
+    drv = ShardedCemDriver(pl, I, world_size=G, always_exchange=distributed)
 
     def one_plan(i):
-        if G == 1:
+        if not distributed:
             return pl.plan(pb['state'], seed=2026, call=i)
         return drv.plan(pb['state'], seed=2026, call=i)
 
@@ -126,7 +129,7 @@ def main():
     pl.set_timing(True)
     roll_ms, roll_n = 0.0, 0
     for i in range(5):
-        if G == 1:
+        if not distributed:
             pl.plan(pb['state'], seed=2027, call=i)
         else:
             drv.plan(pb['state'], seed=2027, call=i)

@@ -1,0 +1,53 @@
+"""bench.py's contract on the GPU box: the default single-process line, and the multi-rank leg (process group over RCCL,
+stepwise plan with the score all-gather, barrier + max-over-ranks timing) rehearsed with one rank under
+torch.distributed.run — the only rehearsal a one-GPU box allows (CEM_BENCH_FORCE_DIST=1)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+        'data', 'config', 'roofline'}
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith('{') and '"metric"' in l]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def _check(r, steps, warmup):
+    assert KEYS <= set(r)
+    assert r['metric'] == 'planning steps/sec (CEM-MPC, N=2000 K=5 H=30)' and r['unit'] == 'plans/s' and r['n_gpus'] == 1
+    assert r['steps'] == steps and r['warmup'] == warmup and r['higher_is_better'] is True and r['scaling'] == 'weak'
+    assert r['dtype'] == 'f32' and r['vs_baseline'] is None and r['data'] == 'synthetic' and 'workload' in r['config']
+    assert abs(r['value'] * r['ms_per_step'] / 1e3 - 1.0) < 1e-6 and r['value'] > 100
+    rf = r['roofline']
+    assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
+    assert 0.3 < rf['frac'] < 1.0
+
+
+def test_default_bench_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '5', '--warmup', '2', '--no-cpu-baseline'],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = _json_line(out.stdout)
+    _check(r, 5, 2)
+    assert r['config']['hip_graph'] is True
+
+
+def test_distributed_leg_with_one_rank_over_rccl():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, CEM_BENCH_FORCE_DIST='1')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+                          '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '5',
+                          '--warmup', '2', '--no-cpu-baseline'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = _json_line(out.stdout)
+    _check(r, 5, 2)
+    assert r['config']['hip_graph'] is False                  # the multi-rank leg launches stepwise around the collective
