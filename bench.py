@@ -23,6 +23,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
+PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 SHADER_CLOCK_HZ = 2.4e9            # MI355X peak engine clock (MI355X_MICROARCH.md)
 
 
@@ -162,6 +163,7 @@ def main():
         'candidate_trajectory_steps_per_s': plans_per_s * I * N * H,
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'mfma_busy_frac': mfma_util,
+                     'hbm_gbps': (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None, 'hbm_peak_gbps': PEAK_HBM_GBPS,
                      'kernel': 'cem_rollout_kernel', 'avg_launch_ms': avg_ms, 'launches_timed': roll_n,
                      'algorithmic_flops_per_launch': flops_launch},
     }
