@@ -806,7 +806,7 @@ struct cem_trainer {
     cem_train_config_t cfg;
     char *ws; hipStream_t stream; bool own_stream;
     size_t nat, scratch_pm;
-    size_t oW, oM, oV, oG, oS, oL, total;
+    size_t oW, oM, oV, oG, oS, oL, oT, total;
 };
 
 namespace {
@@ -831,6 +831,7 @@ void train_layout(cem_trainer *t)
     auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
     t->oW = take(t->nat * c.ensemble_size * 4); t->oM = take(t->nat * c.ensemble_size * 4); t->oV = take(t->nat * c.ensemble_size * 4);
     t->oG = take(t->nat * c.ensemble_size * 4); t->oS = take(t->scratch_pm * c.ensemble_size * 4); t->oL = take((size_t)c.ensemble_size * 2 * 4);
+    t->oT = take(32 * sizeof(long long));            // phase stamps of -DCEM_STAMPS diagnostic builds: the LAST 256 B of the workspace
     t->total = o;
 }
 void fill_train_params(const cem_trainer *t, TrainParams &p)
@@ -842,6 +843,7 @@ void fill_train_params(const cem_trainer *t, TrainParams &p)
     p.D = c.inputs_dim; p.O = c.outputs_dim; p.U = c.units; p.L = c.n_layers; p.E = c.ensemble_size;
     p.nat = (uint32_t)t->nat; p.scratch_per_member = (uint32_t)t->scratch_pm;
     p.beta1 = c.beta1; p.beta2 = c.beta2; p.eps = c.epsilon; p.clip = c.clipvalue;
+    p.stamps = (long long *)(t->ws + t->oT);
 }
 }  // namespace
 
@@ -911,7 +913,7 @@ int cem_trainer_step(cem_trainer_t *t, const float *x_dev, const float *y_dev, c
     if (perm_dev && offset + bt > nperm) return CEM_ERR_INVALID_ARG;
     TrainParams p; fill_train_params(t, p);
     p.x = x_dev; p.y = y_dev; p.perm = perm_dev; p.nperm = nperm; p.offset = offset; p.Bt = bt; p.lr_t = lr_t; p.loss_out = loss_dev; p.train = 1;
-    hipLaunchKernelGGL(cem_train_step_kernel, dim3(t->cfg.ensemble_size), dim3(256), 0, t->stream, p);
+    hipLaunchKernelGGL(cem_train_step_kernel, dim3(t->cfg.ensemble_size), dim3(CEM_TNT), 0, t->stream, p);
     const size_t n4 = (size_t)p.E * p.nat / 4;
     const unsigned adam_grid = (unsigned)std::min<size_t>(std::max<size_t>((n4 + 255) / 256, 1), 2048);
     hipLaunchKernelGGL(cem_adam_kernel, dim3(adam_grid), dim3(256), 0, t->stream, p);
@@ -929,7 +931,7 @@ int cem_trainer_eval(cem_trainer_t *t, const float *x_dev, const float *y_dev, i
     p.x = x_dev; p.y = y_dev; p.perm = nullptr; p.loss_out = (float *)(t->ws + t->oL); p.train = 0;
     for (int off = 0; off < n; off += t->cfg.batch_size) {
         p.offset = off; p.Bt = std::min(t->cfg.batch_size, n - off);
-        hipLaunchKernelGGL(cem_train_step_kernel, dim3(E), dim3(256), 0, t->stream, p);
+        hipLaunchKernelGGL(cem_train_step_kernel, dim3(E), dim3(CEM_TNT), 0, t->stream, p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(part.data(), t->ws + t->oL, part.size() * 4, hipMemcpyDeviceToHost, t->stream));
         HIPCHK(hipStreamSynchronize(t->stream));

@@ -3,9 +3,11 @@
 // tf.keras.optimizers.Adam(lr, clipvalue=1.0, epsilon=1e-5) (:113-117).
 //
 // One workgroup per ensemble member (the members are independent: their own minibatch, weights and Adam moments).
-// A training step is ~28 MFLOP per member in 17 small GEMMs (batch <= 64): latency-bound by construction, so this is a
-// plain LDS-tiled fp32 FMA GEMM (the fp32 MFMA has the same peak rate as the vector FMA on gfx950), everything L2
-// resident.  Weights stay in the Keras layout ([in][out]) the planner's set_weights() consumes.
+// A training step is ~28 MFLOP per member in 17 small dependent GEMMs (batch <= 64): latency-bound by construction, so this
+// is a plain LDS-tiled fp32 FMA GEMM (the fp32 MFMA has the same peak rate as the packed vector FMA on gfx950), everything
+// L2 resident.  The workgroup is 512 threads (two waves per SIMD: the partner hides LDS / L2 latency) and its output tile
+// 64 x 128, so every layer is ONE pass over its K dimension.  Weights stay in the Keras layout ([in][out]) the planner's
+// set_weights() consumes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,57 +26,95 @@ struct TrainParams {
     float lr_t, beta1, beta2, eps, clip;
     float *loss_out;             // train: [E] loss share of each member; eval: [E][2] raw sums (log term, squared term)
     int32_t train;
+    long long *stamps;           // [32] phase stamps (member 0), written by -DCEM_STAMPS diagnostic builds only
 };
 
+#ifdef CEM_STAMPS
+#define CEM_TR_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) p.stamps[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CEM_TR_STAMP(i) do { } while (0)
+#endif
+
 // C(m,n) = sum_k A(m,k) B(k,n) with A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]; epi(m, n, value).
-// 64x64 output tile per pass, k in slabs of CEM_TK staged through a double-buffered LDS tile; the next slab's global
-// loads are issued into registers before the current slab's FMAs, so the L2 latency hides behind the arithmetic and a
-// slab costs one barrier.
+// 64 x 128 output tile per pass (512 threads x 4x4 micro-tiles), k in slabs of CEM_TK staged through a double-buffered LDS
+// tile; the next slab's global loads are issued into registers before the current slab's FMAs, so the L2 latency hides
+// behind the arithmetic and a slab costs one barrier.
+#define CEM_TNT 512                                     // threads per workgroup
 #define CEM_TK 32
-#define CEM_TRAIN_LDS_FLOATS (2 * 2 * CEM_TK * 68)
-template <class Epi>
-__device__ __forceinline__ void wg_gemm(const int M, const int N, const int K, const float *A, const int sam, const int sak,
-                                        const float *B, const int sbk, const int sbn, Epi epi, float *lds)
+#define CEM_TM 64
+#define CEM_TN 128
+#define CEM_TRAIN_LDS_FLOATS (2 * CEM_TK * (CEM_TM + 4) + 2 * CEM_TK * (CEM_TN + 4))
+// the workgroup's GEMM staging tiles (also the scratch of the small reductions between GEMMs); file scope so that the
+// non-inlined GEMM addresses it as LDS
+__shared__ __attribute__((aligned(16))) float g_train_lds[CEM_TRAIN_LDS_FLOATS];
+
+typedef const __attribute__((address_space(1))) float *gcptr;       // global memory, said explicitly: inside a non-inlined
+typedef __attribute__((address_space(1))) float *gptr;              // function a generic pointer would become flat accesses
+
+// what happens to C(m,n) = sum_k A(m,k) B(k,n):  v = C + bias[n];  v += out[m][n] (accum);  v = max(v, 0) (relu);
+// v = gate[m][n] > 0 ? v : 0;  out[m][n] = v.   One body for all 17 GEMMs of a step: inlined per call site the kernel was
+// ~70 KB of straight-line code, more than the instruction cache, and every step streamed its instructions from L2.
+struct GemmEpi {
+    gptr out; int ldo;
+    gcptr bias;            // [N] or null
+    gcptr gate; int ldg;   // [M][ldg] or null
+    int relu, accum;
+};
+
+__device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, const int K, const gcptr Ag, const int sam, const int sak,
+                                                  const gcptr Bg, const int sbk, const int sbn, const GemmEpi e)
 {
-    typedef float Tile[CEM_TK][68];
-    Tile *As = reinterpret_cast<Tile *>(lds);                       // As[buf][k][m]
-    Tile *Bs = reinterpret_cast<Tile *>(lds + 2 * CEM_TK * 68);     // Bs[buf][k][n]
-    constexpr int NE = 64 * CEM_TK / 256;                           // elements per thread per operand slab
-    const int tid = threadIdx.x, tm = tid >> 4, tn = tid & 15;
+    float *lds = g_train_lds;
+    typedef float TileA[CEM_TK][CEM_TM + 4];
+    typedef float TileB[CEM_TK][CEM_TN + 4];
+    TileA *As = reinterpret_cast<TileA *>(lds);                                    // As[buf][k][m]
+    TileB *Bs = reinterpret_cast<TileB *>(lds + 2 * CEM_TK * (CEM_TM + 4));        // Bs[buf][k][n]
+    constexpr int NEA = CEM_TM * CEM_TK / CEM_TNT, NEB = CEM_TN * CEM_TK / CEM_TNT;   // elements per thread per operand slab
+    const int tid = threadIdx.x, tm = tid >> 5, tn = tid & 31;                     // 16 row groups x 32 column groups of 4
     const int nk = (K + CEM_TK - 1) / CEM_TK;
-    for (int m0 = 0; m0 < M; m0 += 64) {
-        for (int n0 = 0; n0 < N; n0 += 64) {
+    for (int m0 = 0; m0 < M; m0 += CEM_TM) {
+        for (int n0 = 0; n0 < N; n0 += CEM_TN) {
             float acc[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int jn = 0; jn < 4; ++jn) acc[i][jn] = 0.f;
-            float ra[NE], rb[NE];
+            float ra[NEA], rb[NEB];
+            auto a_idx = [&](const int q, int &mm, int &kk) {
+                const int el = tid + CEM_TNT * q;
+                if (sak == 1) { kk = el % CEM_TK; mm = el / CEM_TK; } else { mm = el % CEM_TM; kk = el / CEM_TM; }   // coalesce along the unit stride
+            };
+            auto b_idx = [&](const int q, int &nn, int &kb) {
+                const int el = tid + CEM_TNT * q;
+                if (sbn == 1) { nn = el % CEM_TN; kb = el / CEM_TN; } else { kb = el % CEM_TK; nn = el / CEM_TK; }
+            };
+            // loads are unconditional on clamped indices and zeroed afterwards: a guarded load `ok ? A[i] : 0` compiles to a
+            // branch around the load with a wait behind it, i.e. the slab's loads go out one L2 round trip at a time
             auto fetch = [&](const int k0) {
 #pragma unroll
-                for (int q = 0; q < NE; ++q) {
-                    const int e = tid + 256 * q;
-                    int mm, kk;
-                    if (sak == 1) { kk = e % CEM_TK; mm = e / CEM_TK; } else { mm = e & 63; kk = e >> 6; }      // coalesce along the unit stride
+                for (int q = 0; q < NEA; ++q) {
+                    int mm, kk; a_idx(q, mm, kk);
                     const int gm = m0 + mm, gk = k0 + kk;
-                    ra[q] = (gm < M && gk < K) ? A[(size_t)gm * sam + (size_t)gk * sak] : 0.f;
-                    int nn, kb;
-                    if (sbn == 1) { nn = e & 63; kb = e >> 6; } else { kb = e % CEM_TK; nn = e / CEM_TK; }
-                    const int gn = n0 + nn, gkb = k0 + kb;
-                    rb[q] = (gn < N && gkb < K) ? B[(size_t)gkb * sbk + (size_t)gn * sbn] : 0.f;
+                    const int cm = gm < M ? gm : M - 1, ck = gk < K ? gk : K - 1;
+                    ra[q] = Ag[(size_t)cm * sam + (size_t)ck * sak];
                 }
+#pragma unroll
+                for (int q = 0; q < NEB; ++q) {
+                    int nn, kb; b_idx(q, nn, kb);
+                    const int gn = n0 + nn, gkb = k0 + kb;
+                    const int cn = gn < N ? gn : N - 1, ck = gkb < K ? gkb : K - 1;
+                    rb[q] = Bg[(size_t)ck * sbk + (size_t)cn * sbn];
+                }
+#pragma unroll
+                for (int q = 0; q < NEA; ++q) { int mm, kk; a_idx(q, mm, kk); if (m0 + mm >= M || k0 + kk >= K) ra[q] = 0.f; }
+#pragma unroll
+                for (int q = 0; q < NEB; ++q) { int nn, kb; b_idx(q, nn, kb); if (n0 + nn >= N || k0 + kb >= K) rb[q] = 0.f; }
             };
             auto stash = [&](const int buf) {
 #pragma unroll
-                for (int q = 0; q < NE; ++q) {
-                    const int e = tid + 256 * q;
-                    int mm, kk;
-                    if (sak == 1) { kk = e % CEM_TK; mm = e / CEM_TK; } else { mm = e & 63; kk = e >> 6; }
-                    As[buf][kk][mm] = ra[q];
-                    int nn, kb;
-                    if (sbn == 1) { nn = e & 63; kb = e >> 6; } else { kb = e % CEM_TK; nn = e / CEM_TK; }
-                    Bs[buf][kb][nn] = rb[q];
-                }
+                for (int q = 0; q < NEA; ++q) { int mm, kk; a_idx(q, mm, kk); As[buf][kk][mm] = ra[q]; }
+#pragma unroll
+                for (int q = 0; q < NEB; ++q) { int nn, kb; b_idx(q, nn, kb); Bs[buf][kb][nn] = rb[q]; }
             };
             fetch(0);
             stash(0);
@@ -82,7 +122,7 @@ __device__ __forceinline__ void wg_gemm(const int M, const int N, const int K, c
             for (int kt = 0; kt < nk; ++kt) {
                 const int buf = kt & 1;
                 if (kt + 1 < nk) fetch((kt + 1) * CEM_TK);
-#pragma unroll
+#pragma unroll 8
                 for (int kk = 0; kk < CEM_TK; ++kk) {
                     const float4 a = *reinterpret_cast<const float4 *>(&As[buf][kk][tm * 4]);
                     const float4 b = *reinterpret_cast<const float4 *>(&Bs[buf][kk][tn * 4]);
@@ -95,13 +135,49 @@ __device__ __forceinline__ void wg_gemm(const int M, const int N, const int K, c
                 if (kt + 1 < nk) stash(buf ^ 1);
                 __syncthreads();
             }
+            // epilogue: the optional operands (bias, previous value, gate) are loaded as batches on clamped indices, too
+            {
+                float bia[4], prv[4][4], gat[4][4];
+                size_t oidx[4][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int jn = 0; jn < 4; ++jn) {
-                    const int m = m0 + tm * 4 + i, n = n0 + tn * 4 + jn;
-                    if (m < M && n < N) epi(m, n, acc[i][jn]);
+                    for (int jn = 0; jn < 4; ++jn) {
+                        const int mI = m0 + tm * 4 + i, n = n0 + tn * 4 + jn;
+                        const int cm = mI < M ? mI : M - 1, cn = n < N ? n : N - 1;
+                        oidx[i][jn] = (size_t)cm * e.ldo + cn;
+                        prv[i][jn] = 0.f; gat[i][jn] = 1.f;
+                    }
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn) { const int n = n0 + tn * 4 + jn; bia[jn] = e.bias ? e.bias[n < N ? n : N - 1] : 0.f; }
+                if (e.accum) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < 4; ++jn) prv[i][jn] = e.out[oidx[i][jn]];
                 }
+                if (e.gate) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < 4; ++jn) {
+                            const int mI = m0 + tm * 4 + i, n = n0 + tn * 4 + jn;
+                            gat[i][jn] = e.gate[(size_t)(mI < M ? mI : M - 1) * e.ldg + (n < N ? n : N - 1)];
+                        }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < 4; ++jn) {
+                        const int mI = m0 + tm * 4 + i, n = n0 + tn * 4 + jn;
+                        float v = acc[i][jn];
+                        if (e.bias) v = v + bia[jn];
+                        if (e.accum) v = prv[i][jn] + v;
+                        if (e.relu) v = fmaxf(v, 0.f);
+                        if (e.gate) v = gat[i][jn] > 0.f ? v : 0.f;
+                        if (mI < M && n < N) e.out[oidx[i][jn]] = v;
+                    }
+            }
         }
     }
     __syncthreads();
@@ -116,18 +192,18 @@ __device__ __forceinline__ float train_softplus(float x)         // Eigen's thre
     return log1pf(ex);
 }
 
-// Elementwise pass over n items with the loads of CEM_UNR items in flight at once: one wave per SIMD has nobody to hide a
-// load behind, so a plain `for (e = tid; ...)` loop pays the whole L2 latency every iteration.
-#define CEM_UNR 8
+// Elementwise pass over n items with the loads of CEM_UNR items in flight at once: with one or two waves per SIMD a plain
+// `for (e = tid; ...)` loop pays most of the L2 latency every iteration.
+#define CEM_UNR 4
 template <class T, class Ld, class St>
 __device__ __forceinline__ void wg_map(const int n, Ld ld, St st)
 {
-    for (int base = 0; base < n; base += 256 * CEM_UNR) {
+    for (int base = 0; base < n; base += CEM_TNT * CEM_UNR) {
         T v[CEM_UNR];
 #pragma unroll
-        for (int q = 0; q < CEM_UNR; ++q) { const int e = base + q * 256 + (int)threadIdx.x; if (e < n) v[q] = ld(e); }
+        for (int q = 0; q < CEM_UNR; ++q) { const int e = base + q * CEM_TNT + (int)threadIdx.x; if (e < n) v[q] = ld(e); }
 #pragma unroll
-        for (int q = 0; q < CEM_UNR; ++q) { const int e = base + q * 256 + (int)threadIdx.x; if (e < n) st(e, v[q]); }
+        for (int q = 0; q < CEM_UNR; ++q) { const int e = base + q * CEM_TNT + (int)threadIdx.x; if (e < n) st(e, v[q]); }
     }
 }
 
@@ -139,15 +215,17 @@ __device__ __forceinline__ float block_sum(float v, float *red)
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
-    const float t = red[0] + red[1] + red[2] + red[3];
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < CEM_TNT / 64; ++i) t = t + red[i];
     __syncthreads();
     return t;
 }
 
-__global__ __launch_bounds__(256) void cem_train_step_kernel(const TrainParams p)
+__global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainParams p)
 {
-    __shared__ __attribute__((aligned(16))) float lds[CEM_TRAIN_LDS_FLOATS];
-    __shared__ float red[4];
+    float *lds = g_train_lds;
+    __shared__ float red[CEM_TNT / 64];
     const int m = blockIdx.x, tid = threadIdx.x;
     const int D = p.D, O = p.O, U = p.U, L = p.L, Bt = p.Bt;
     float *W = p.W + (size_t)m * p.nat, *G = p.grad + (size_t)m * p.nat;
@@ -168,6 +246,7 @@ __global__ __launch_bounds__(256) void cem_train_step_kernel(const TrainParams p
     const size_t oWmu = (size_t)D * U + U + (size_t)(L - 1) * ((size_t)U * U + U), obmu = oWmu + (size_t)U * O;
     const size_t oWv = obmu + O, obv = oWv + (size_t)U * O;
 
+    CEM_TR_STAMP(0);
     // ---- gather the minibatch ---------------------------------------------------------------------------------
     {
         int32_t *rows = reinterpret_cast<int32_t *>(lds);
@@ -180,17 +259,20 @@ __global__ __launch_bounds__(256) void cem_train_step_kernel(const TrainParams p
     }
     __syncthreads();
 
+    CEM_TR_STAMP(1);
     // ---- forward (mlp_ensemble.py:18-22,33-34,59-61) -----------------------------------------------------------
     for (int l = 0; l < L; ++l) {
         const float *hin = l == 0 ? xs : hs + (size_t)(l - 1) * CEM_TB * U;
         float *hout = hs + (size_t)l * CEM_TB * U;
         const float *Wl = W + offW(l), *bl = W + offb(l);
-        wg_gemm(Bt, U, l == 0 ? D : U, hin, U, 1, Wl, U, 1, [&](int r, int n, float v) { hout[r * U + n] = fmaxf(v + bl[n], 0.f); }, lds);
+        wg_gemm(Bt, U, l == 0 ? D : U, (gcptr)hin, U, 1, (gcptr)Wl, U, 1, GemmEpi{(gptr)hout, U, (gcptr)bl, nullptr, 0, 1, 0});     // relu(h W + b)
     }
+    CEM_TR_STAMP(2);
     const float *hL = hs + (size_t)(L - 1) * CEM_TB * U;
-    wg_gemm(Bt, O, U, hL, U, 1, W + oWmu, O, 1, [&](int r, int n, float v) { mu[r * U + n] = v + W[obmu + n]; }, lds);
-    wg_gemm(Bt, O, U, hL, U, 1, W + oWv, O, 1, [&](int r, int n, float v) { vp[r * U + n] = v + W[obv + n]; }, lds);
+    wg_gemm(Bt, O, U, (gcptr)hL, U, 1, (gcptr)(W + oWmu), O, 1, GemmEpi{(gptr)mu, U, (gcptr)(W + obmu), nullptr, 0, 0, 0});
+    wg_gemm(Bt, O, U, (gcptr)hL, U, 1, (gcptr)(W + oWv), O, 1, GemmEpi{(gptr)vp, U, (gcptr)(W + obv), nullptr, 0, 0, 0});
 
+    CEM_TR_STAMP(3);
     // ---- negative_log_likelihood (:64-67) and its gradient w.r.t. mu and the pre-softplus variance -----------------
     float s_log = 0.f, s_sq = 0.f;
     const float ninv = 1.0f / ((float)Bt * (float)O * (float)p.E);
@@ -210,6 +292,7 @@ __global__ __launch_bounds__(256) void cem_train_step_kernel(const TrainParams p
         });
     s_log = block_sum(s_log, red);
     s_sq = block_sum(s_sq, red);
+    CEM_TR_STAMP(4);
     if (!p.train) {
         if (tid == 0) { p.loss_out[2 * m] = s_log; p.loss_out[2 * m + 1] = s_sq; }
         return;
@@ -217,41 +300,50 @@ __global__ __launch_bounds__(256) void cem_train_step_kernel(const TrainParams p
     if (tid == 0) p.loss_out[m] = (0.5f * s_log / ((float)Bt * (float)O) + 0.5f * s_sq / ((float)Bt * (float)O)) / (float)p.E;
     __syncthreads();
 
+    CEM_TR_STAMP(5);
     // ---- backward ------------------------------------------------------------------------------------------------
-    // column sums (bias gradients) of a [Bt][U]-strided matrix: two half-sums over the even / odd rows, added in that order
+    // column sums (bias gradients) of a [Bt][U]-strided matrix: CEM_TNT/128 partial sums over interleaved rows, added in order
     float *colred = lds;
     auto col_sums = [&](const float *src, const int ncol, float *dst) {
+        constexpr int NP = CEM_TNT / 128;
         for (int c0 = 0; c0 < ncol; c0 += 128) {
-            const int c = c0 + (tid & 127), half = tid >> 7;
+            const int c = c0 + (tid & 127), part = tid >> 7;
             float a = 0.f;
             if (c < ncol) {
 #pragma unroll 8
-                for (int r = half; r < Bt; r += 2) a += src[r * U + c];
+                for (int r = part; r < Bt; r += NP) a += src[r * U + c];
             }
             colred[tid] = a;
             __syncthreads();
-            if (tid < 128 && c < ncol) dst[c] = colred[tid] + colred[tid + 128];
+            if (tid < 128 && c < ncol) {
+                float t = colred[tid];
+#pragma unroll
+                for (int q = 1; q < NP; ++q) t = t + colred[tid + 128 * q];
+                dst[c] = t;
+            }
             __syncthreads();
         }
     };
-    wg_gemm(U, O, Bt, hL, 1, U, dmu, U, 1, [&](int u, int n, float v) { G[oWmu + (size_t)u * O + n] = v; }, lds);
-    wg_gemm(U, O, Bt, hL, 1, U, dv, U, 1, [&](int u, int n, float v) { G[oWv + (size_t)u * O + n] = v; }, lds);
+    wg_gemm(U, O, Bt, (gcptr)hL, 1, U, (gcptr)dmu, U, 1, GemmEpi{(gptr)(G + oWmu), O, nullptr, nullptr, 0, 0, 0});                  // dW_mu = h_L^T dmu
+    wg_gemm(U, O, Bt, (gcptr)hL, 1, U, (gcptr)dv, U, 1, GemmEpi{(gptr)(G + oWv), O, nullptr, nullptr, 0, 0, 0});
     col_sums(dmu, O, G + obmu);
     col_sums(dv, O, G + obv);
     // dh_L = (dmu Wmu^T + dv Wvar^T) * relu'(h_L): the relu mask rides in the epilogue of the GEMM that completes dh
-    wg_gemm(Bt, U, O, dmu, U, 1, W + oWmu, 1, O, [&](int r, int n, float v) { dha[r * U + n] = v; }, lds);
-    wg_gemm(Bt, U, O, dv, U, 1, W + oWv, 1, O, [&](int r, int n, float v) { dha[r * U + n] = hL[r * U + n] > 0.f ? dha[r * U + n] + v : 0.f; }, lds);
+    wg_gemm(Bt, U, O, (gcptr)dmu, U, 1, (gcptr)(W + oWmu), 1, O, GemmEpi{(gptr)dha, U, nullptr, nullptr, 0, 0, 0});
+    wg_gemm(Bt, U, O, (gcptr)dv, U, 1, (gcptr)(W + oWv), 1, O, GemmEpi{(gptr)dha, U, nullptr, (gcptr)hL, U, 0, 1});
+    CEM_TR_STAMP(6);
     float *dcur = dha, *dnext = dhb;
     for (int l = L - 1; l >= 0; --l) {
         const float *hin = l == 0 ? xs : hs + (size_t)(l - 1) * CEM_TB * U;
         const int in = l == 0 ? D : U;
-        wg_gemm(in, U, Bt, hin, 1, U, dcur, U, 1, [&](int i, int n, float v) { G[offW(l) + (size_t)i * U + n] = v; }, lds);
+        wg_gemm(in, U, Bt, (gcptr)hin, 1, U, (gcptr)dcur, U, 1, GemmEpi{(gptr)(G + offW(l)), U, nullptr, nullptr, 0, 0, 0});        // dW_l = h_{l-1}^T dh_l
         col_sums(dcur, U, G + offb(l));
         if (l > 0) {
-            wg_gemm(Bt, U, U, dcur, U, 1, W + offW(l), 1, U, [&](int r, int n, float v) { dnext[r * U + n] = hin[r * U + n] > 0.f ? v : 0.f; }, lds);
+            wg_gemm(Bt, U, U, (gcptr)dcur, U, 1, (gcptr)(W + offW(l)), 1, U, GemmEpi{(gptr)dnext, U, nullptr, (gcptr)hin, U, 0, 0});   // dh_{l-1} = (dh_l W_l^T) relu'
             float *t = dcur; dcur = dnext; dnext = t;
         }
     }
+    CEM_TR_STAMP(7);
 }
 
 // ---- Adam with clipvalue (mlp_ensemble.py:113-117,143-144), every member's parameters in one grid ---------------------
