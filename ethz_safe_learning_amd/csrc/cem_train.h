@@ -59,10 +59,17 @@ struct GemmEpi {
     gcptr bias;            // [N] or null
     gcptr gate; int ldg;   // [M][ldg] or null
     int relu, accum;
+    // optional column split (the mu | variance head pair as ONE GEMM): columns n >= nsplit go to out1 / bias1 at n - nsplit
+    gptr out1; gcptr bias1;
 };
 
+// operand split of the fused head GEMMs: B(k, n) comes from B1 at (k - ksplit, n) for k >= ksplit or at (k, n - nsplit) for
+// n >= nsplit; A(m, k) from A1 at (m, k - ksplit).  Unused splits are INT_MAX.
+struct GemmSplit { gcptr A1, B1; int ksplit, nsplit; };
+#define CEM_NOSPLIT GemmSplit{nullptr, nullptr, 0x7fffffff, 0x7fffffff}
+
 __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, const int K, const gcptr Ag, const int sam, const int sak,
-                                                  const gcptr Bg, const int sbk, const int sbn, const GemmEpi e)
+                                                  const gcptr Bg, const int sbk, const int sbn, const GemmEpi e, const GemmSplit sp)
 {
     float *lds = g_train_lds;
     typedef float TileA[CEM_TK][CEM_TM + 4];
@@ -96,14 +103,17 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
                     int mm, kk; a_idx(q, mm, kk);
                     const int gm = m0 + mm, gk = k0 + kk;
                     const int cm = gm < M ? gm : M - 1, ck = gk < K ? gk : K - 1;
-                    ra[q] = Ag[(size_t)cm * sam + (size_t)ck * sak];
+                    const bool a0 = ck < sp.ksplit;                      // pointer and index are selected, then ONE unconditional load
+                    const gcptr ap = a0 ? Ag : sp.A1;
+                    ra[q] = ap[(size_t)cm * sam + (size_t)(a0 ? ck : ck - sp.ksplit) * sak];
                 }
 #pragma unroll
                 for (int q = 0; q < NEB; ++q) {
                     int nn, kb; b_idx(q, nn, kb);
                     const int gn = n0 + nn, gkb = k0 + kb;
                     const int cn = gn < N ? gn : N - 1, ck = gkb < K ? gkb : K - 1;
-                    rb[q] = Bg[(size_t)ck * sbk + (size_t)cn * sbn];
+                    const gcptr bp = (ck < sp.ksplit && cn < sp.nsplit) ? Bg : sp.B1;
+                    rb[q] = bp[(size_t)(ck < sp.ksplit ? ck : ck - sp.ksplit) * sbk + (size_t)(cn < sp.nsplit ? cn : cn - sp.nsplit) * sbn];
                 }
 #pragma unroll
                 for (int q = 0; q < NEA; ++q) { int mm, kk; a_idx(q, mm, kk); if (m0 + mm >= M || k0 + kk >= K) ra[q] = 0.f; }
@@ -145,16 +155,20 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
                     for (int jn = 0; jn < 4; ++jn) {
                         const int mI = m0 + tm * 4 + i, n = n0 + tn * 4 + jn;
                         const int cm = mI < M ? mI : M - 1, cn = n < N ? n : N - 1;
-                        oidx[i][jn] = (size_t)cm * e.ldo + cn;
+                        oidx[i][jn] = (size_t)cm * e.ldo + (cn < sp.nsplit ? cn : cn - sp.nsplit);
                         prv[i][jn] = 0.f; gat[i][jn] = 1.f;
                     }
 #pragma unroll
-                for (int jn = 0; jn < 4; ++jn) { const int n = n0 + tn * 4 + jn; bia[jn] = e.bias ? e.bias[n < N ? n : N - 1] : 0.f; }
+                for (int jn = 0; jn < 4; ++jn) {
+                    const int n = n0 + tn * 4 + jn, cn = n < N ? n : N - 1;
+                    const gcptr bp = cn < sp.nsplit ? e.bias : e.bias1;
+                    bia[jn] = e.bias ? bp[cn < sp.nsplit ? cn : cn - sp.nsplit] : 0.f;
+                }
                 if (e.accum) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int jn = 0; jn < 4; ++jn) prv[i][jn] = e.out[oidx[i][jn]];
+                        for (int jn = 0; jn < 4; ++jn) prv[i][jn] = (n0 + tn * 4 + jn < sp.nsplit ? e.out : e.out1)[oidx[i][jn]];
                 }
                 if (e.gate) {
 #pragma unroll
@@ -175,7 +189,7 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
                         if (e.accum) v = prv[i][jn] + v;
                         if (e.relu) v = fmaxf(v, 0.f);
                         if (e.gate) v = gat[i][jn] > 0.f ? v : 0.f;
-                        if (mI < M && n < N) e.out[oidx[i][jn]] = v;
+                        if (mI < M && n < N) (n < sp.nsplit ? e.out : e.out1)[oidx[i][jn]] = v;
                     }
             }
         }
@@ -265,13 +279,13 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
         const float *hin = l == 0 ? xs : hs + (size_t)(l - 1) * CEM_TB * U;
         float *hout = hs + (size_t)l * CEM_TB * U;
         const float *Wl = W + offW(l), *bl = W + offb(l);
-        wg_gemm(Bt, U, l == 0 ? D : U, (gcptr)hin, U, 1, (gcptr)Wl, U, 1, GemmEpi{(gptr)hout, U, (gcptr)bl, nullptr, 0, 1, 0});     // relu(h W + b)
+        wg_gemm(Bt, U, l == 0 ? D : U, (gcptr)hin, U, 1, (gcptr)Wl, U, 1, GemmEpi{(gptr)hout, U, (gcptr)bl, nullptr, 0, 1, 0, nullptr, nullptr}, CEM_NOSPLIT);     // relu(h W + b)
     }
     CEM_TR_STAMP(2);
     const float *hL = hs + (size_t)(L - 1) * CEM_TB * U;
-    wg_gemm(Bt, O, U, (gcptr)hL, U, 1, (gcptr)(W + oWmu), O, 1, GemmEpi{(gptr)mu, U, (gcptr)(W + obmu), nullptr, 0, 0, 0});
-    wg_gemm(Bt, O, U, (gcptr)hL, U, 1, (gcptr)(W + oWv), O, 1, GemmEpi{(gptr)vp, U, (gcptr)(W + obv), nullptr, 0, 0, 0});
-
+    // both heads as ONE GEMM: columns [0, O) = mu head, [O, 2O) = variance head (2O <= 128 fills the tile two N = O GEMMs half use)
+    wg_gemm(Bt, 2 * O, U, (gcptr)hL, U, 1, (gcptr)(W + oWmu), O, 1,
+            GemmEpi{(gptr)mu, U, (gcptr)(W + obmu), nullptr, 0, 0, 0, (gptr)vp, (gcptr)(W + obv)}, GemmSplit{nullptr, (gcptr)(W + oWv), 0x7fffffff, O});
     CEM_TR_STAMP(3);
     // ---- negative_log_likelihood (:64-67) and its gradient w.r.t. mu and the pre-softplus variance -----------------
     float s_log = 0.f, s_sq = 0.f;
@@ -324,22 +338,24 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
             __syncthreads();
         }
     };
-    wg_gemm(U, O, Bt, (gcptr)hL, 1, U, (gcptr)dmu, U, 1, GemmEpi{(gptr)(G + oWmu), O, nullptr, nullptr, 0, 0, 0});                  // dW_mu = h_L^T dmu
-    wg_gemm(U, O, Bt, (gcptr)hL, 1, U, (gcptr)dv, U, 1, GemmEpi{(gptr)(G + oWv), O, nullptr, nullptr, 0, 0, 0});
+    // [dW_mu | dW_var] = h_L^T [dmu | dv] as one GEMM
+    wg_gemm(U, 2 * O, Bt, (gcptr)hL, 1, U, (gcptr)dmu, U, 1,
+            GemmEpi{(gptr)(G + oWmu), O, nullptr, nullptr, 0, 0, 0, (gptr)(G + oWv), nullptr}, GemmSplit{nullptr, (gcptr)dv, 0x7fffffff, O});
     col_sums(dmu, O, G + obmu);
     col_sums(dv, O, G + obv);
     // dh_L = (dmu Wmu^T + dv Wvar^T) * relu'(h_L): the relu mask rides in the epilogue of the GEMM that completes dh
-    wg_gemm(Bt, U, O, (gcptr)dmu, U, 1, (gcptr)(W + oWmu), 1, O, GemmEpi{(gptr)dha, U, nullptr, nullptr, 0, 0, 0});
-    wg_gemm(Bt, U, O, (gcptr)dv, U, 1, (gcptr)(W + oWv), 1, O, GemmEpi{(gptr)dha, U, nullptr, (gcptr)hL, U, 0, 1});
+    // dh_L = ([dmu | dv] [W_mu | W_var]^T) * relu'(h_L): one GEMM over K = 2O; the relu mask rides in its epilogue
+    wg_gemm(Bt, U, 2 * O, (gcptr)dmu, U, 1, (gcptr)(W + oWmu), 1, O,
+            GemmEpi{(gptr)dha, U, nullptr, (gcptr)hL, U, 0, 0, nullptr, nullptr}, GemmSplit{(gcptr)dv, (gcptr)(W + oWv), O, 0x7fffffff});
     CEM_TR_STAMP(6);
     float *dcur = dha, *dnext = dhb;
     for (int l = L - 1; l >= 0; --l) {
         const float *hin = l == 0 ? xs : hs + (size_t)(l - 1) * CEM_TB * U;
         const int in = l == 0 ? D : U;
-        wg_gemm(in, U, Bt, (gcptr)hin, 1, U, (gcptr)dcur, U, 1, GemmEpi{(gptr)(G + offW(l)), U, nullptr, nullptr, 0, 0, 0});        // dW_l = h_{l-1}^T dh_l
+        wg_gemm(in, U, Bt, (gcptr)hin, 1, U, (gcptr)dcur, U, 1, GemmEpi{(gptr)(G + offW(l)), U, nullptr, nullptr, 0, 0, 0, nullptr, nullptr}, CEM_NOSPLIT);        // dW_l = h_{l-1}^T dh_l
         col_sums(dcur, U, G + offb(l));
         if (l > 0) {
-            wg_gemm(Bt, U, U, (gcptr)dcur, U, 1, (gcptr)(W + offW(l)), 1, U, GemmEpi{(gptr)dnext, U, nullptr, (gcptr)hin, U, 0, 0});   // dh_{l-1} = (dh_l W_l^T) relu'
+            wg_gemm(Bt, U, U, (gcptr)dcur, U, 1, (gcptr)(W + offW(l)), 1, U, GemmEpi{(gptr)dnext, U, nullptr, (gcptr)hin, U, 0, 0, nullptr, nullptr}, CEM_NOSPLIT);   // dh_{l-1} = (dh_l W_l^T) relu'
             float *t = dcur; dcur = dnext; dnext = t;
         }
     }
