@@ -43,7 +43,8 @@ struct TrainParams {
 #define CEM_TK 32
 #define CEM_TM 64
 #define CEM_TN 128
-#define CEM_TRAIN_LDS_FLOATS (2 * CEM_TK * (CEM_TM + 4) + 2 * CEM_TK * (CEM_TN + 4))
+#define CEM_TPAD 16                                     // row stride = 16 (mod 64) words: the 4 k-rows of an MFMA operand read hit disjoint banks
+#define CEM_TRAIN_LDS_FLOATS (2 * CEM_TK * (CEM_TM + CEM_TPAD) + 2 * CEM_TK * (CEM_TN + CEM_TPAD))
 // the workgroup's GEMM staging tiles (also the scratch of the small reductions between GEMMs); file scope so that the
 // non-inlined GEMM addresses it as LDS
 __shared__ __attribute__((aligned(16))) float g_train_lds[CEM_TRAIN_LDS_FLOATS];
@@ -72,21 +73,24 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
                                                   const gcptr Bg, const int sbk, const int sbn, const GemmEpi e, const GemmSplit sp)
 {
     float *lds = g_train_lds;
-    typedef float TileA[CEM_TK][CEM_TM + 4];
-    typedef float TileB[CEM_TK][CEM_TN + 4];
+    typedef float TileA[CEM_TK][CEM_TM + CEM_TPAD];
+    typedef float TileB[CEM_TK][CEM_TN + CEM_TPAD];
     TileA *As = reinterpret_cast<TileA *>(lds);                                    // As[buf][k][m]
-    TileB *Bs = reinterpret_cast<TileB *>(lds + 2 * CEM_TK * (CEM_TM + 4));        // Bs[buf][k][n]
+    TileB *Bs = reinterpret_cast<TileB *>(lds + 2 * CEM_TK * (CEM_TM + CEM_TPAD));   // Bs[buf][k][n]
     constexpr int NEA = CEM_TM * CEM_TK / CEM_TNT, NEB = CEM_TN * CEM_TK / CEM_TNT;   // elements per thread per operand slab
-    const int tid = threadIdx.x, tm = tid >> 5, tn = tid & 31;                     // 16 row groups x 32 column groups of 4
+    // MFMA 16x16x4 core: wave w owns rows [16 rb, +16) x columns [64 ch, +64) of the tile as four 16x16 blocks; lane (kq, i)
+    // feeds A[16 rb + i][4P + kq] and B[4P + kq][64 ch + 16 cb + i]; the block's D has rows 4 kq + r, column i on the lane.
+    // Each loaded operand word serves 16 FMAs (4x4 micro-tiles: 2), which takes the kernel off the LDS-bandwidth bound; the
+    // hardware accumulates k in ascending order, the same chain the FMA version ran.
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, rb = wv & 3, ch = wv >> 2, kq = lane >> 4, li = lane & 15;
     const int nk = (K + CEM_TK - 1) / CEM_TK;
     for (int m0 = 0; m0 < M; m0 += CEM_TM) {
         for (int n0 = 0; n0 < N; n0 += CEM_TN) {
-            float acc[4][4];
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            f4v acc[4];                                   // acc[cb][r] = C[16 rb + 4 kq + r][64 ch + 16 cb + li]
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int jn = 0; jn < 4; ++jn) acc[i][jn] = 0.f;
-            float ra[NEA], rb[NEB];
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = (f4v){0.f, 0.f, 0.f, 0.f};
+            float ra[NEA], rbuf[NEB];
             auto a_idx = [&](const int q, int &mm, int &kk) {
                 const int el = tid + CEM_TNT * q;
                 if (sak == 1) { kk = el % CEM_TK; mm = el / CEM_TK; } else { mm = el % CEM_TM; kk = el / CEM_TM; }   // coalesce along the unit stride
@@ -113,18 +117,18 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
                     const int gn = n0 + nn, gkb = k0 + kb;
                     const int cn = gn < N ? gn : N - 1, ck = gkb < K ? gkb : K - 1;
                     const gcptr bp = (ck < sp.ksplit && cn < sp.nsplit) ? Bg : sp.B1;
-                    rb[q] = bp[(size_t)(ck < sp.ksplit ? ck : ck - sp.ksplit) * sbk + (size_t)(cn < sp.nsplit ? cn : cn - sp.nsplit) * sbn];
+                    rbuf[q] = bp[(size_t)(ck < sp.ksplit ? ck : ck - sp.ksplit) * sbk + (size_t)(cn < sp.nsplit ? cn : cn - sp.nsplit) * sbn];
                 }
 #pragma unroll
                 for (int q = 0; q < NEA; ++q) { int mm, kk; a_idx(q, mm, kk); if (m0 + mm >= M || k0 + kk >= K) ra[q] = 0.f; }
 #pragma unroll
-                for (int q = 0; q < NEB; ++q) { int nn, kb; b_idx(q, nn, kb); if (n0 + nn >= N || k0 + kb >= K) rb[q] = 0.f; }
+                for (int q = 0; q < NEB; ++q) { int nn, kb; b_idx(q, nn, kb); if (n0 + nn >= N || k0 + kb >= K) rbuf[q] = 0.f; }
             };
             auto stash = [&](const int buf) {
 #pragma unroll
                 for (int q = 0; q < NEA; ++q) { int mm, kk; a_idx(q, mm, kk); As[buf][kk][mm] = ra[q]; }
 #pragma unroll
-                for (int q = 0; q < NEB; ++q) { int nn, kb; b_idx(q, nn, kb); Bs[buf][kb][nn] = rb[q]; }
+                for (int q = 0; q < NEB; ++q) { int nn, kb; b_idx(q, nn, kb); Bs[buf][kb][nn] = rbuf[q]; }
             };
             fetch(0);
             stash(0);
@@ -132,15 +136,14 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
             for (int kt = 0; kt < nk; ++kt) {
                 const int buf = kt & 1;
                 if (kt + 1 < nk) fetch((kt + 1) * CEM_TK);
-#pragma unroll 8
-                for (int kk = 0; kk < CEM_TK; ++kk) {
-                    const float4 a = *reinterpret_cast<const float4 *>(&As[buf][kk][tm * 4]);
-                    const float4 b = *reinterpret_cast<const float4 *>(&Bs[buf][kk][tn * 4]);
-                    const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                for (int P = 0; P < CEM_TK / 4; ++P) {
+                    const float a = As[buf][4 * P + kq][16 * rb + li];
+                    float b[4];
 #pragma unroll
-                        for (int jn = 0; jn < 4; ++jn) acc[i][jn] = __builtin_fmaf(av[i], bv[jn], acc[i][jn]);
+                    for (int cb = 0; cb < 4; ++cb) b[cb] = Bs[buf][4 * P + kq][64 * ch + 16 * cb + li];
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[cb], acc[cb], 0, 0, 0);
                 }
                 if (kt + 1 < nk) stash(buf ^ 1);
                 __syncthreads();
@@ -153,14 +156,14 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int jn = 0; jn < 4; ++jn) {
-                        const int mI = m0 + tm * 4 + i, n = n0 + tn * 4 + jn;
+                        const int mI = m0 + 16 * rb + 4 * kq + i, n = n0 + 64 * ch + 16 * jn + li;
                         const int cm = mI < M ? mI : M - 1, cn = n < N ? n : N - 1;
                         oidx[i][jn] = (size_t)cm * e.ldo + (cn < sp.nsplit ? cn : cn - sp.nsplit);
                         prv[i][jn] = 0.f; gat[i][jn] = 1.f;
                     }
 #pragma unroll
                 for (int jn = 0; jn < 4; ++jn) {
-                    const int n = n0 + tn * 4 + jn, cn = n < N ? n : N - 1;
+                    const int n = n0 + 64 * ch + 16 * jn + li, cn = n < N ? n : N - 1;
                     const gcptr bp = cn < sp.nsplit ? e.bias : e.bias1;
                     bia[jn] = e.bias ? bp[cn < sp.nsplit ? cn : cn - sp.nsplit] : 0.f;
                 }
@@ -168,14 +171,14 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int jn = 0; jn < 4; ++jn) prv[i][jn] = (n0 + tn * 4 + jn < sp.nsplit ? e.out : e.out1)[oidx[i][jn]];
+                        for (int jn = 0; jn < 4; ++jn) prv[i][jn] = (n0 + 64 * ch + 16 * jn + li < sp.nsplit ? e.out : e.out1)[oidx[i][jn]];
                 }
                 if (e.gate) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int jn = 0; jn < 4; ++jn) {
-                            const int mI = m0 + tm * 4 + i, n = n0 + tn * 4 + jn;
+                            const int mI = m0 + 16 * rb + 4 * kq + i, n = n0 + 64 * ch + 16 * jn + li;
                             gat[i][jn] = e.gate[(size_t)(mI < M ? mI : M - 1) * e.ldg + (n < N ? n : N - 1)];
                         }
                 }
@@ -183,8 +186,8 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int jn = 0; jn < 4; ++jn) {
-                        const int mI = m0 + tm * 4 + i, n = n0 + tn * 4 + jn;
-                        float v = acc[i][jn];
+                        const int mI = m0 + 16 * rb + 4 * kq + i, n = n0 + 64 * ch + 16 * jn + li;
+                        float v = acc[jn][i];
                         if (e.bias) v = v + bia[jn];
                         if (e.accum) v = prv[i][jn] + v;
                         if (e.relu) v = fmaxf(v, 0.f);
