@@ -62,6 +62,7 @@ struct GemmEpi {
     int relu, accum;
     // optional column split (the mu | variance head pair as ONE GEMM): columns n >= nsplit go to out1 / bias1 at n - nsplit
     gptr out1; gcptr bias1;
+    long long *st;         // -DCEM_STAMPS builds: accumulates [8] prologue (first slab in LDS), [9] k loop, [10] epilogue cycles of member 0
 };
 
 // operand split of the fused head GEMMs: B(k, n) comes from B1 at (k - ksplit, n) for k >= ksplit or at (k, n - nsplit) for
@@ -130,9 +131,15 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
 #pragma unroll
                 for (int q = 0; q < NEB; ++q) { int nn, kb; b_idx(q, nn, kb); Bs[buf][kb][nn] = rbuf[q]; }
             };
+#ifdef CEM_STAMPS
+            long long t0_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
             fetch(0);
             stash(0);
             __syncthreads();
+#ifdef CEM_STAMPS
+            long long t1_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
             for (int kt = 0; kt < nk; ++kt) {
                 const int buf = kt & 1;
                 if (kt + 1 < nk) fetch((kt + 1) * CEM_TK);
@@ -148,6 +155,9 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
                 if (kt + 1 < nk) stash(buf ^ 1);
                 __syncthreads();
             }
+#ifdef CEM_STAMPS
+            long long t2_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
             // epilogue: the optional operands (bias, previous value, gate) are loaded as batches on clamped indices, too
             {
                 float bia[4], prv[4][4], gat[4][4];
@@ -195,6 +205,9 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
                         if (mI < M && n < N) (n < sp.nsplit ? e.out : e.out1)[oidx[i][jn]] = v;
                     }
             }
+#ifdef CEM_STAMPS
+            if (e.st && blockIdx.x == 0 && tid == 0) { const long long t3_ = (long long)__builtin_amdgcn_s_memtime(); e.st[8] += t1_ - t0_; e.st[9] += t2_ - t1_; e.st[10] += t3_ - t2_; e.st[11] += 1; }
+#endif
         }
     }
     __syncthreads();
@@ -264,6 +277,9 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
     const size_t oWv = obmu + O, obv = oWv + (size_t)U * O;
 
     CEM_TR_STAMP(0);
+#ifdef CEM_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) { p.stamps[8] = p.stamps[9] = p.stamps[10] = p.stamps[11] = 0; }
+#endif
     // ---- gather the minibatch ---------------------------------------------------------------------------------
     {
         int32_t *rows = reinterpret_cast<int32_t *>(lds);
@@ -282,13 +298,13 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
         const float *hin = l == 0 ? xs : hs + (size_t)(l - 1) * CEM_TB * U;
         float *hout = hs + (size_t)l * CEM_TB * U;
         const float *Wl = W + offW(l), *bl = W + offb(l);
-        wg_gemm(Bt, U, l == 0 ? D : U, (gcptr)hin, U, 1, (gcptr)Wl, U, 1, GemmEpi{(gptr)hout, U, (gcptr)bl, nullptr, 0, 1, 0, nullptr, nullptr}, CEM_NOSPLIT);     // relu(h W + b)
+        wg_gemm(Bt, U, l == 0 ? D : U, (gcptr)hin, U, 1, (gcptr)Wl, U, 1, GemmEpi{(gptr)hout, U, (gcptr)bl, nullptr, 0, 1, 0, nullptr, nullptr, p.stamps}, CEM_NOSPLIT);     // relu(h W + b)
     }
     CEM_TR_STAMP(2);
     const float *hL = hs + (size_t)(L - 1) * CEM_TB * U;
     // both heads as ONE GEMM: columns [0, O) = mu head, [O, 2O) = variance head (2O <= 128 fills the tile two N = O GEMMs half use)
     wg_gemm(Bt, 2 * O, U, (gcptr)hL, U, 1, (gcptr)(W + oWmu), O, 1,
-            GemmEpi{(gptr)mu, U, (gcptr)(W + obmu), nullptr, 0, 0, 0, (gptr)vp, (gcptr)(W + obv)}, GemmSplit{nullptr, (gcptr)(W + oWv), 0x7fffffff, O});
+            GemmEpi{(gptr)mu, U, (gcptr)(W + obmu), nullptr, 0, 0, 0, (gptr)vp, (gcptr)(W + obv), p.stamps}, GemmSplit{nullptr, (gcptr)(W + oWv), 0x7fffffff, O});
     CEM_TR_STAMP(3);
     // ---- negative_log_likelihood (:64-67) and its gradient w.r.t. mu and the pre-softplus variance -----------------
     float s_log = 0.f, s_sq = 0.f;
@@ -343,22 +359,22 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
     };
     // [dW_mu | dW_var] = h_L^T [dmu | dv] as one GEMM
     wg_gemm(U, 2 * O, Bt, (gcptr)hL, 1, U, (gcptr)dmu, U, 1,
-            GemmEpi{(gptr)(G + oWmu), O, nullptr, nullptr, 0, 0, 0, (gptr)(G + oWv), nullptr}, GemmSplit{nullptr, (gcptr)dv, 0x7fffffff, O});
+            GemmEpi{(gptr)(G + oWmu), O, nullptr, nullptr, 0, 0, 0, (gptr)(G + oWv), nullptr, p.stamps}, GemmSplit{nullptr, (gcptr)dv, 0x7fffffff, O});
     col_sums(dmu, O, G + obmu);
     col_sums(dv, O, G + obv);
     // dh_L = (dmu Wmu^T + dv Wvar^T) * relu'(h_L): the relu mask rides in the epilogue of the GEMM that completes dh
     // dh_L = ([dmu | dv] [W_mu | W_var]^T) * relu'(h_L): one GEMM over K = 2O; the relu mask rides in its epilogue
     wg_gemm(Bt, U, 2 * O, (gcptr)dmu, U, 1, (gcptr)(W + oWmu), 1, O,
-            GemmEpi{(gptr)dha, U, nullptr, (gcptr)hL, U, 0, 0, nullptr, nullptr}, GemmSplit{(gcptr)dv, (gcptr)(W + oWv), O, 0x7fffffff});
+            GemmEpi{(gptr)dha, U, nullptr, (gcptr)hL, U, 0, 0, nullptr, nullptr, p.stamps}, GemmSplit{(gcptr)dv, (gcptr)(W + oWv), O, 0x7fffffff});
     CEM_TR_STAMP(6);
     float *dcur = dha, *dnext = dhb;
     for (int l = L - 1; l >= 0; --l) {
         const float *hin = l == 0 ? xs : hs + (size_t)(l - 1) * CEM_TB * U;
         const int in = l == 0 ? D : U;
-        wg_gemm(in, U, Bt, (gcptr)hin, 1, U, (gcptr)dcur, U, 1, GemmEpi{(gptr)(G + offW(l)), U, nullptr, nullptr, 0, 0, 0, nullptr, nullptr}, CEM_NOSPLIT);        // dW_l = h_{l-1}^T dh_l
+        wg_gemm(in, U, Bt, (gcptr)hin, 1, U, (gcptr)dcur, U, 1, GemmEpi{(gptr)(G + offW(l)), U, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, p.stamps}, CEM_NOSPLIT);        // dW_l = h_{l-1}^T dh_l
         col_sums(dcur, U, G + offb(l));
         if (l > 0) {
-            wg_gemm(Bt, U, U, (gcptr)dcur, U, 1, (gcptr)(W + offW(l)), 1, U, GemmEpi{(gptr)dnext, U, nullptr, (gcptr)hin, U, 0, 0, nullptr, nullptr}, CEM_NOSPLIT);   // dh_{l-1} = (dh_l W_l^T) relu'
+            wg_gemm(Bt, U, U, (gcptr)dcur, U, 1, (gcptr)(W + offW(l)), 1, U, GemmEpi{(gptr)dnext, U, nullptr, (gcptr)hin, U, 0, 0, nullptr, nullptr, p.stamps}, CEM_NOSPLIT);   // dh_{l-1} = (dh_l W_l^T) relu'
             float *t = dcur; dcur = dnext; dnext = t;
         }
     }

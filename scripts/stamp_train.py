@@ -21,3 +21,4 @@ ws = tr._ws_view
 st = ws[ws.numel() - 256:].view(torch.int64).cpu().numpy().astype(np.float64)
 names = ['gather', 'forward hidden layers', 'forward heads', 'nll + grads', '(branch)', 'backward heads', 'backward layers']
 print('  '.join('%s %.1f us' % (nm, (st[i + 1] - st[i]) / 2400.0) for i, nm in enumerate(names)), ' total %.1f us' % ((st[7] - st[0]) / 2400.0))
+print('inside the %d GEMM tile passes: first slab into LDS %.1f us, k loop %.1f us, epilogue %.1f us' % (st[11], st[8] / 2400.0, st[9] / 2400.0, st[10] / 2400.0))
