@@ -52,14 +52,14 @@ __shared__ __attribute__((aligned(16))) float g_train_lds[CEM_TRAIN_LDS_FLOATS];
 typedef const __attribute__((address_space(1))) float *gcptr;       // global memory, said explicitly: inside a non-inlined
 typedef __attribute__((address_space(1))) float *gptr;              // function a generic pointer would become flat accesses
 
-// what happens to C(m,n) = sum_k A(m,k) B(k,n):  v = C + bias[n];  v += out[m][n] (accum);  v = max(v, 0) (relu);
-// v = gate[m][n] > 0 ? v : 0;  out[m][n] = v.   One body for all 17 GEMMs of a step: inlined per call site the kernel was
+// what happens to C(m,n) = sum_k A(m,k) B(k,n):  v = C + bias[n];  v = max(v, 0) (relu);  v = gate[m][n] > 0 ? v : 0;
+// out[m][n] = v.   One body for all 17 GEMMs of a step: inlined per call site the kernel was
 // ~70 KB of straight-line code, more than the instruction cache, and every step streamed its instructions from L2.
 struct GemmEpi {
     gptr out; int ldo;
     gcptr bias;            // [N] or null
     gcptr gate; int ldg;   // [M][ldg] or null
-    int relu, accum;
+    int relu;
     // optional column split (the mu | variance head pair as ONE GEMM): columns n >= nsplit go to out1 / bias1 at n - nsplit
     gptr out1; gcptr bias1;
     long long *st;         // -DCEM_STAMPS builds: accumulates [8] prologue (first slab in LDS), [9] k loop, [10] epilogue cycles of member 0
@@ -140,6 +140,23 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
 #ifdef CEM_STAMPS
             long long t1_ = (long long)__builtin_amdgcn_s_memtime();
 #endif
+            // epilogue operands, requested now (batched, clamped indices) so that their latency hides behind the k loop
+            float bia[4], gat[4][4];
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) {
+                const int n = n0 + 64 * ch + 16 * jn + li, cn = n < N ? n : N - 1;
+                const gcptr bp = cn < sp.nsplit ? e.bias : e.bias1;
+                bia[jn] = e.bias ? bp[cn < sp.nsplit ? cn : cn - sp.nsplit] : 0.f;
+            }
+            if (e.gate) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < 4; ++jn) {
+                        const int mI = m0 + 16 * rb + 4 * kq + i, n = n0 + 64 * ch + 16 * jn + li;
+                        gat[i][jn] = e.gate[(mI < M ? mI : M - 1) * e.ldg + (n < N ? n : N - 1)];
+                    }
+            }
             for (int kt = 0; kt < nk; ++kt) {
                 const int buf = kt & 1;
                 if (kt + 1 < nk) fetch((kt + 1) * CEM_TK);
@@ -158,53 +175,18 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
 #ifdef CEM_STAMPS
             long long t2_ = (long long)__builtin_amdgcn_s_memtime();
 #endif
-            // epilogue: the optional operands (bias, previous value, gate) are loaded as batches on clamped indices, too
-            {
-                float bia[4], prv[4][4], gat[4][4];
-                size_t oidx[4][4];
+            // epilogue (its bias / gate operands were requested before the k loop)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int jn = 0; jn < 4; ++jn) {
-                        const int mI = m0 + 16 * rb + 4 * kq + i, n = n0 + 64 * ch + 16 * jn + li;
-                        const int cm = mI < M ? mI : M - 1, cn = n < N ? n : N - 1;
-                        oidx[i][jn] = (size_t)cm * e.ldo + (cn < sp.nsplit ? cn : cn - sp.nsplit);
-                        prv[i][jn] = 0.f; gat[i][jn] = 1.f;
-                    }
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int jn = 0; jn < 4; ++jn) {
-                    const int n = n0 + 64 * ch + 16 * jn + li, cn = n < N ? n : N - 1;
-                    const gcptr bp = cn < sp.nsplit ? e.bias : e.bias1;
-                    bia[jn] = e.bias ? bp[cn < sp.nsplit ? cn : cn - sp.nsplit] : 0.f;
+                    const int mI = m0 + 16 * rb + 4 * kq + i, n = n0 + 64 * ch + 16 * jn + li;
+                    float v = acc[jn][i];
+                    if (e.bias) v = v + bia[jn];
+                    if (e.relu) v = fmaxf(v, 0.f);
+                    if (e.gate) v = gat[i][jn] > 0.f ? v : 0.f;
+                    if (mI < M && n < N) (n < sp.nsplit ? e.out : e.out1)[(mI < M ? mI : M - 1) * e.ldo + (n < sp.nsplit ? n : n - sp.nsplit)] = v;
                 }
-                if (e.accum) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int jn = 0; jn < 4; ++jn) prv[i][jn] = (n0 + 64 * ch + 16 * jn + li < sp.nsplit ? e.out : e.out1)[oidx[i][jn]];
-                }
-                if (e.gate) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int jn = 0; jn < 4; ++jn) {
-                            const int mI = m0 + 16 * rb + 4 * kq + i, n = n0 + 64 * ch + 16 * jn + li;
-                            gat[i][jn] = e.gate[(size_t)(mI < M ? mI : M - 1) * e.ldg + (n < N ? n : N - 1)];
-                        }
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int jn = 0; jn < 4; ++jn) {
-                        const int mI = m0 + 16 * rb + 4 * kq + i, n = n0 + 64 * ch + 16 * jn + li;
-                        float v = acc[jn][i];
-                        if (e.bias) v = v + bia[jn];
-                        if (e.accum) v = prv[i][jn] + v;
-                        if (e.relu) v = fmaxf(v, 0.f);
-                        if (e.gate) v = gat[i][jn] > 0.f ? v : 0.f;
-                        if (mI < M && n < N) (n < sp.nsplit ? e.out : e.out1)[oidx[i][jn]] = v;
-                    }
-            }
 #ifdef CEM_STAMPS
             if (e.st && blockIdx.x == 0 && tid == 0) { const long long t3_ = (long long)__builtin_amdgcn_s_memtime(); e.st[8] += t1_ - t0_; e.st[9] += t2_ - t1_; e.st[10] += t3_ - t2_; e.st[11] += 1; }
 #endif
@@ -298,13 +280,13 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
         const float *hin = l == 0 ? xs : hs + (size_t)(l - 1) * CEM_TB * U;
         float *hout = hs + (size_t)l * CEM_TB * U;
         const float *Wl = W + offW(l), *bl = W + offb(l);
-        wg_gemm(Bt, U, l == 0 ? D : U, (gcptr)hin, U, 1, (gcptr)Wl, U, 1, GemmEpi{(gptr)hout, U, (gcptr)bl, nullptr, 0, 1, 0, nullptr, nullptr, p.stamps}, CEM_NOSPLIT);     // relu(h W + b)
+        wg_gemm(Bt, U, l == 0 ? D : U, (gcptr)hin, U, 1, (gcptr)Wl, U, 1, GemmEpi{(gptr)hout, U, (gcptr)bl, nullptr, 0, 1, nullptr, nullptr, p.stamps}, CEM_NOSPLIT);     // relu(h W + b)
     }
     CEM_TR_STAMP(2);
     const float *hL = hs + (size_t)(L - 1) * CEM_TB * U;
     // both heads as ONE GEMM: columns [0, O) = mu head, [O, 2O) = variance head (2O <= 128 fills the tile two N = O GEMMs half use)
     wg_gemm(Bt, 2 * O, U, (gcptr)hL, U, 1, (gcptr)(W + oWmu), O, 1,
-            GemmEpi{(gptr)mu, U, (gcptr)(W + obmu), nullptr, 0, 0, 0, (gptr)vp, (gcptr)(W + obv), p.stamps}, GemmSplit{nullptr, (gcptr)(W + oWv), 0x7fffffff, O});
+            GemmEpi{(gptr)mu, U, (gcptr)(W + obmu), nullptr, 0, 0, (gptr)vp, (gcptr)(W + obv), p.stamps}, GemmSplit{nullptr, (gcptr)(W + oWv), 0x7fffffff, O});
     CEM_TR_STAMP(3);
     // ---- negative_log_likelihood (:64-67) and its gradient w.r.t. mu and the pre-softplus variance -----------------
     float s_log = 0.f, s_sq = 0.f;
@@ -359,22 +341,22 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
     };
     // [dW_mu | dW_var] = h_L^T [dmu | dv] as one GEMM
     wg_gemm(U, 2 * O, Bt, (gcptr)hL, 1, U, (gcptr)dmu, U, 1,
-            GemmEpi{(gptr)(G + oWmu), O, nullptr, nullptr, 0, 0, 0, (gptr)(G + oWv), nullptr, p.stamps}, GemmSplit{nullptr, (gcptr)dv, 0x7fffffff, O});
+            GemmEpi{(gptr)(G + oWmu), O, nullptr, nullptr, 0, 0, (gptr)(G + oWv), nullptr, p.stamps}, GemmSplit{nullptr, (gcptr)dv, 0x7fffffff, O});
     col_sums(dmu, O, G + obmu);
     col_sums(dv, O, G + obv);
     // dh_L = (dmu Wmu^T + dv Wvar^T) * relu'(h_L): the relu mask rides in the epilogue of the GEMM that completes dh
     // dh_L = ([dmu | dv] [W_mu | W_var]^T) * relu'(h_L): one GEMM over K = 2O; the relu mask rides in its epilogue
     wg_gemm(Bt, U, 2 * O, (gcptr)dmu, U, 1, (gcptr)(W + oWmu), 1, O,
-            GemmEpi{(gptr)dha, U, nullptr, (gcptr)hL, U, 0, 0, nullptr, nullptr, p.stamps}, GemmSplit{(gcptr)dv, (gcptr)(W + oWv), O, 0x7fffffff});
+            GemmEpi{(gptr)dha, U, nullptr, (gcptr)hL, U, 0, nullptr, nullptr, p.stamps}, GemmSplit{(gcptr)dv, (gcptr)(W + oWv), O, 0x7fffffff});
     CEM_TR_STAMP(6);
     float *dcur = dha, *dnext = dhb;
     for (int l = L - 1; l >= 0; --l) {
         const float *hin = l == 0 ? xs : hs + (size_t)(l - 1) * CEM_TB * U;
         const int in = l == 0 ? D : U;
-        wg_gemm(in, U, Bt, (gcptr)hin, 1, U, (gcptr)dcur, U, 1, GemmEpi{(gptr)(G + offW(l)), U, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, p.stamps}, CEM_NOSPLIT);        // dW_l = h_{l-1}^T dh_l
+        wg_gemm(in, U, Bt, (gcptr)hin, 1, U, (gcptr)dcur, U, 1, GemmEpi{(gptr)(G + offW(l)), U, nullptr, nullptr, 0, 0, nullptr, nullptr, p.stamps}, CEM_NOSPLIT);        // dW_l = h_{l-1}^T dh_l
         col_sums(dcur, U, G + offb(l));
         if (l > 0) {
-            wg_gemm(Bt, U, U, (gcptr)dcur, U, 1, (gcptr)(W + offW(l)), 1, U, GemmEpi{(gptr)dnext, U, nullptr, (gcptr)hin, U, 0, 0, nullptr, nullptr, p.stamps}, CEM_NOSPLIT);   // dh_{l-1} = (dh_l W_l^T) relu'
+            wg_gemm(Bt, U, U, (gcptr)dcur, U, 1, (gcptr)(W + offW(l)), 1, U, GemmEpi{(gptr)dnext, U, nullptr, (gcptr)hin, U, 0, nullptr, nullptr, p.stamps}, CEM_NOSPLIT);   // dh_{l-1} = (dh_l W_l^T) relu'
             float *t = dcur; dcur = dnext; dnext = t;
         }
     }
