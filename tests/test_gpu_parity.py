@@ -123,6 +123,37 @@ def test_rollout_scores_match_oracle(variant, P, E, N, H, post):
         assert (ref64 < -50).any() and (ref64 > -50).any(), 'test should see both safe and unsafe candidates'
 
 
+@pytest.mark.parametrize('seed', range(12))
+def test_rollout_scores_random_shapes(seed):
+    """Seeded random sweep over the shape / flag space (obs, act, E, particles per member, N, H, objective, tile size,
+    sampling_propagation, scale_features): per-candidate scores of one iteration against the fp64 oracle on explicit noise."""
+    torch = _torch()
+    rng = np.random.default_rng(1000 + seed)
+    O, A = [(40, 2), (60, 2), (60, 3), (72, 2), (100, 12), (100, 2)][rng.integers(6)]
+    E = int(rng.integers(1, 7)); P = E * int(rng.integers(1, 3))
+    N = int(rng.integers(17, 141)); H = int(rng.integers(1, 13))
+    variant = ['cem', 'safe'][rng.integers(2)]
+    rc = int(rng.integers(0, 5))
+    sampling, scale = bool(rng.integers(2)), bool(rng.integers(2))
+    pb = hp.make_problem(O, A, E, 4, seed=500 + seed)
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=max(1, N // 10), I=1, variant=variant, post=0.3, sampling=sampling, scale=scale,
+                            chunks_per_tile=rc)
+    pl = hp.make_planner(pb, pcfg)
+    ea, em, eo = hp.noise(1, N, H, A, P, O, seed=seed)
+    actions, returns, scores = _run_iteration(pl, pb, ocfg, ea, em)
+    lb, ub, mu0, sg0 = o.sampling_params(pb['low'], pb['high'])
+    ref_actions = o.sample_actions(np.broadcast_to(mu0, (H, A)), np.broadcast_to(sg0, (H, A)), lb, ub, ea[0])
+    np.testing.assert_array_equal(actions, ref_actions)
+    ref64, traj64 = o.candidate_scores(pb['state'].astype(np.float64), ref_actions.astype(np.float64), o.cast_weights(pb['weights'], np.float64),
+                                       pb['inputs_min'], pb['inputs_max'], em[0], ocfg, pb['scorer'], return_traj=True)
+    ok = o.threshold_margins(traj64, pb['scorer']).reshape(P, N).min(axis=0) > 1e-4
+    assert ok.mean() > 0.5
+    err = np.abs(scores - ref64)[ok].max()
+    print('seed %d: O=%d A=%d E=%d P=%d N=%d H=%d %s rc=%d sampling=%s scale=%s: max|gpu-f64| = %.3g over %d/%d'
+          % (seed, O, A, E, P, N, H, variant, rc, sampling, scale, err, ok.sum(), N))
+    assert err <= ATOL
+
+
 def test_select_is_exact_on_given_scores():
     """top_k / best-so-far / moments on the scores the GPU itself produced: elite set bit-exact vs the oracle."""
     torch = _torch()
