@@ -110,7 +110,7 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
                     const int cm = gm < M ? gm : M - 1, ck = gk < K ? gk : K - 1;
                     const bool a0 = ck < sp.ksplit;                      // pointer and index are selected, then ONE unconditional load
                     const gcptr ap = a0 ? Ag : sp.A1;
-                    ra[q] = ap[(size_t)cm * sam + (size_t)(a0 ? ck : ck - sp.ksplit) * sak];
+                    ra[q] = ap[cm * sam + (a0 ? ck : ck - sp.ksplit) * sak];           // 32-bit offsets: every operand is < 2^31 floats
                 }
 #pragma unroll
                 for (int q = 0; q < NEB; ++q) {
@@ -118,7 +118,7 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
                     const int gn = n0 + nn, gkb = k0 + kb;
                     const int cn = gn < N ? gn : N - 1, ck = gkb < K ? gkb : K - 1;
                     const gcptr bp = (ck < sp.ksplit && cn < sp.nsplit) ? Bg : sp.B1;
-                    rbuf[q] = bp[(size_t)(ck < sp.ksplit ? ck : ck - sp.ksplit) * sbk + (size_t)(cn < sp.nsplit ? cn : cn - sp.nsplit) * sbn];
+                    rbuf[q] = bp[(ck < sp.ksplit ? ck : ck - sp.ksplit) * sbk + (cn < sp.nsplit ? cn : cn - sp.nsplit) * sbn];
                 }
 #pragma unroll
                 for (int q = 0; q < NEA; ++q) { int mm, kk; a_idx(q, mm, kk); if (m0 + mm >= M || k0 + kk >= K) ra[q] = 0.f; }
