@@ -175,3 +175,29 @@ def test_tiles_partition_property(built_lib, E, ppm, nmul, world, chunks, obs, d
     rc, tiles = plan_tiles(cfg)
     assert 1 <= rc <= 4 and (chunks == 0 or rc == chunks)
     _check_tiles(cfg, rc, tiles)
+
+
+def test_makefile_rebuilds_on_any_header_change(tmp_path):
+    """A header missing from the library target's prerequisites means timing (or testing) a stale binary after a
+    header-only edit — that happened with cem_train.h.  `make -q` must report 'out of date' when any header is newer."""
+    import glob
+    import shutil
+    import subprocess
+    import time
+    src = os.path.join(ROOT, 'ethz_safe_learning_amd', 'csrc')
+    work = tmp_path / 'ethz_safe_learning_amd' / 'csrc'
+    shutil.copytree(src, work)
+    shutil.copytree(os.path.join(ROOT, 'include'), tmp_path / 'include')
+    (tmp_path / 'ethz_safe_learning_amd' / 'lib').mkdir()
+    lib = tmp_path / 'ethz_safe_learning_amd' / 'lib' / 'libcem_mpc_gfx950.so'
+    headers = sorted(glob.glob(str(work / '*.h')) + glob.glob(str(tmp_path / 'include' / '*.h')))
+    assert len(headers) >= 3
+    for h in headers:
+        now = time.time()
+        for f in glob.glob(str(work / '*')) + headers:
+            os.utime(f, (now - 100, now - 100))
+        lib.write_bytes(b'')                                  # a "built" library, newer than every source
+        os.utime(lib, (now - 50, now - 50))
+        assert subprocess.run(['make', '-q', '-C', str(work)]).returncode == 0, 'up to date expected'
+        os.utime(h, (now, now))                               # touch one header
+        assert subprocess.run(['make', '-q', '-C', str(work)]).returncode == 1, '%s is not a prerequisite' % os.path.basename(h)
