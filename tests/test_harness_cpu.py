@@ -106,3 +106,32 @@ def test_reference_experiment_names_resolve_to_presets(tmp_path):
     import pytest
     with pytest.raises(FileNotFoundError):
         load_config_or_die(str(tmp_path), 'nonexistent.yaml')
+
+
+def test_env_reward_and_cost_equal_the_scorer_on_its_own_observations():
+    """The planner scores predicted observations with SafetyGymStateScorer (safety_gym.py:110-166); on the stand-in
+    environment's TRUE observations that scorer must reproduce the environment's own reward and cost (within lidar range and
+    away from the goal-bonus step) — i.e. lidar flip, closest-distance metric and reward sign agree end to end."""
+    from oracle import cem_oracle as o
+    from ethz_safe_learning_amd.simba.environment_utils.point_goal_env import PointGoalEnv
+    env = PointGoalEnv(seed=3)
+    rng = np.random.default_rng(1)
+    t = env.sensor_offset_table
+    sp = o.ScorerParams(goal_slice=(t['goal_lidar'].start, t['goal_lidar'].stop),
+                        cost_kinds=[(t['hazards_lidar'].start, t['hazards_lidar'].stop, env.config['hazards_size'])],
+                        lidar_max_dist=env.config['lidar_max_dist'], goal_size=env.config['goal_size'],
+                        reward_distance=env.config['reward_distance'], reward_goal=env.config['reward_goal'])
+    ob = env.reset()
+    worst, checked = 0.0, 0
+    for _ in range(1500):
+        a = rng.uniform(-1, 1, 2)
+        before = np.linalg.norm(env.goal - env.pos)
+        ob2, r, done, info = env.step(a)
+        if not info.get('goal_met'):
+            after = np.linalg.norm(env.goal - env.pos)
+            if before < 2.9 and after < 2.9 and before > 0.8 * env.config['goal_size']:
+                rs, _ = o.reward(ob[None].astype(np.float64), ob2[None].astype(np.float64), sp)
+                worst = max(worst, abs(float(rs[0]) - r)); checked += 1
+            assert float(o.cost(ob2[None].astype(np.float64), sp)[0]) == info['cost']
+        ob = ob2
+    assert checked > 1000 and worst < 1e-12
