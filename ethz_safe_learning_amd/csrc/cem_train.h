@@ -39,7 +39,10 @@ struct TrainParams {
 // 64 x 128 output tile per pass (512 threads x 4x4 micro-tiles), k in slabs of CEM_TK staged through a double-buffered LDS
 // tile; the next slab's global loads are issued into registers before the current slab's FMAs, so the L2 latency hides
 // behind the arithmetic and a slab costs one barrier.
-#define CEM_TNT 512                                     // threads per workgroup
+#ifndef CEM_TNT
+#define CEM_TNT 512                                     // threads per workgroup (8 waves: 2 per SIMD; 1024 measured slower: 262 vs 250 us, spills under the 128-VGPR cap)
+#endif
+#define CEM_NCB (CEM_TN / 16 / (CEM_TNT / 256))         // 16-column blocks per wave: waves = 4 row blocks x (CEM_TNT/256) column groups
 #define CEM_TK 32
 #define CEM_TM 64
 #define CEM_TN 128
@@ -84,13 +87,14 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
     // Each loaded operand word serves 16 FMAs (4x4 micro-tiles: 2), which takes the kernel off the LDS-bandwidth bound; the
     // hardware accumulates k in ascending order, the same chain the FMA version ran.
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, rb = wv & 3, ch = wv >> 2, kq = lane >> 4, li = lane & 15;
+    constexpr int CW = 16 * CEM_NCB;                                               // columns per wave
     const int nk = (K + CEM_TK - 1) / CEM_TK;
     for (int m0 = 0; m0 < M; m0 += CEM_TM) {
         for (int n0 = 0; n0 < N; n0 += CEM_TN) {
             typedef float f4v __attribute__((ext_vector_type(4)));
-            f4v acc[4];                                   // acc[cb][r] = C[16 rb + 4 kq + r][64 ch + 16 cb + li]
+            f4v acc[CEM_NCB];                             // acc[cb][r] = C[16 rb + 4 kq + r][CW ch + 16 cb + li]
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[cb] = (f4v){0.f, 0.f, 0.f, 0.f};
+            for (int cb = 0; cb < CEM_NCB; ++cb) acc[cb] = (f4v){0.f, 0.f, 0.f, 0.f};
             float ra[NEA], rbuf[NEB];
             auto a_idx = [&](const int q, int &mm, int &kk) {
                 const int el = tid + CEM_TNT * q;
@@ -141,10 +145,10 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
             long long t1_ = (long long)__builtin_amdgcn_s_memtime();
 #endif
             // epilogue operands, requested now (batched, clamped indices) so that their latency hides behind the k loop
-            float bia[4], gat[4][4];
+            float bia[CEM_NCB], gat[4][CEM_NCB];
 #pragma unroll
-            for (int jn = 0; jn < 4; ++jn) {
-                const int n = n0 + 64 * ch + 16 * jn + li, cn = n < N ? n : N - 1;
+            for (int jn = 0; jn < CEM_NCB; ++jn) {
+                const int n = n0 + CW * ch + 16 * jn + li, cn = n < N ? n : N - 1;
                 const gcptr bp = cn < sp.nsplit ? e.bias : e.bias1;
                 bia[jn] = e.bias ? bp[cn < sp.nsplit ? cn : cn - sp.nsplit] : 0.f;
             }
@@ -152,8 +156,8 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int jn = 0; jn < 4; ++jn) {
-                        const int mI = m0 + 16 * rb + 4 * kq + i, n = n0 + 64 * ch + 16 * jn + li;
+                    for (int jn = 0; jn < CEM_NCB; ++jn) {
+                        const int mI = m0 + 16 * rb + 4 * kq + i, n = n0 + CW * ch + 16 * jn + li;
                         gat[i][jn] = e.gate[(mI < M ? mI : M - 1) * e.ldg + (n < N ? n : N - 1)];
                     }
             }
@@ -163,11 +167,11 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
 #pragma unroll
                 for (int P = 0; P < CEM_TK / 4; ++P) {
                     const float a = As[buf][4 * P + kq][16 * rb + li];
-                    float b[4];
+                    float b[CEM_NCB];
 #pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) b[cb] = Bs[buf][4 * P + kq][64 * ch + 16 * cb + li];
+                    for (int cb = 0; cb < CEM_NCB; ++cb) b[cb] = Bs[buf][4 * P + kq][CW * ch + 16 * cb + li];
 #pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[cb], acc[cb], 0, 0, 0);
+                    for (int cb = 0; cb < CEM_NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[cb], acc[cb], 0, 0, 0);
                 }
                 if (kt + 1 < nk) stash(buf ^ 1);
                 __syncthreads();
@@ -179,8 +183,8 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int jn = 0; jn < 4; ++jn) {
-                    const int mI = m0 + 16 * rb + 4 * kq + i, n = n0 + 64 * ch + 16 * jn + li;
+                for (int jn = 0; jn < CEM_NCB; ++jn) {
+                    const int mI = m0 + 16 * rb + 4 * kq + i, n = n0 + CW * ch + 16 * jn + li;
                     float v = acc[jn][i];
                     if (e.bias) v = v + bia[jn];
                     if (e.relu) v = fmaxf(v, 0.f);
