@@ -598,7 +598,10 @@ int enqueue_select(cem_planner *h, int it)
     static size_t dyn_limit = 0;
     if (!dyn_limit) {
         dyn_limit = 48 * 1024;
+        // both variants: the uncached one still keeps the elite list (up to 24576 indices = 96 KB) in dynamic LDS
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&cem_select_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                140 * 1024) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&cem_select_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 140 * 1024) == hipSuccess) dyn_limit = 140 * 1024;
         else (void)hipGetLastError();
     }

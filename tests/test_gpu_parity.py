@@ -178,14 +178,15 @@ def test_select_is_exact_on_given_scores():
     assert s == best_score and it == 1
 
 
-@pytest.mark.parametrize('case', ['ties', 'all_equal', 'k_equals_n', 'negatives_and_inf', 'large', 'n16000', 'n40000'])
+@pytest.mark.parametrize('case', ['ties', 'all_equal', 'k_equals_n', 'negatives_and_inf', 'large', 'n16000', 'n40000', 'k20000'])
 def test_select_edge_cases(case):
     """tf.nn.top_k semantics on hand-made score vectors written straight into the score buffer."""
     torch = _torch()
     pb = hp.make_problem(seed=42)
     # n16000: the replicated select of an 8-GPU weak-scaled plan (scores staged in 64 KB of LDS); n40000: beyond the LDS cache
-    N = {'large': 4096, 'n16000': 16000, 'n40000': 40000}.get(case, 64)
-    k = {'ties': 5, 'all_equal': 7, 'k_equals_n': 64, 'negatives_and_inf': 6, 'large': 409, 'n16000': 1600, 'n40000': 4000}[case]
+    # k20000: an elite list of 80 KB in dynamic LDS on the uncached path
+    N = {'large': 4096, 'n16000': 16000, 'n40000': 40000, 'k20000': 60000}.get(case, 64)
+    k = {'ties': 5, 'all_equal': 7, 'k_equals_n': 64, 'negatives_and_inf': 6, 'large': 409, 'n16000': 1600, 'n40000': 4000, 'k20000': 20000}[case]
     H = 3
     ocfg, pcfg = hp.configs(pb, N=N, H=H, P=5, E=5, k=k, I=1)
     pl = hp.make_planner(pb, pcfg)
