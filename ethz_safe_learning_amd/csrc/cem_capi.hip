@@ -39,6 +39,8 @@ int validate(const cem_config_t *c)
     if (c->n_samples % c->world_size != 0) return CEM_ERR_INVALID_ARG;
     if (((long long)c->particles * c->n_samples) % c->ensemble_size != 0) return CEM_ERR_SPLIT;
     if (c->n_elite > 24576) return CEM_ERR_UNSUPPORTED;
+    // the select kernel keeps the elite list and two per-(step, action) arrays in dynamic LDS (140 KB available)
+    if ((size_t)((c->n_elite + 3) & ~3) * 4 + (size_t)2 * c->horizon * c->act_dim * 4 > 140 * 1024) return CEM_ERR_UNSUPPORTED;
     if (c->scorer.n_cost_kinds < 0 || c->scorer.n_cost_kinds > CEM_MAX_COST_KINDS) return CEM_ERR_INVALID_ARG;
     if (c->variant != CEM_VARIANT_CEM && c->variant != CEM_VARIANT_SAFE) return CEM_ERR_INVALID_ARG;
     if (c->chunks_per_tile < 0 || c->chunks_per_tile > 4) return CEM_ERR_INVALID_ARG;

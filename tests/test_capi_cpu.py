@@ -50,6 +50,7 @@ def test_config_struct_matches_header_size(built_lib):
     (dict(particles=3, n_samples=7, n_elite=2, ensemble_size=5), 3),   # tf.split would raise (mlp_ensemble.py:123)
     (dict(n_elite=3000), 1),                             # k > N
     (dict(world_size=3), 1),                             # N % world != 0
+    (dict(horizon=20000), 2),                            # elite list + 2 x H x A floats must fit the select kernel's LDS
 ])
 def test_validation_errors(built_lib, kw, status):
     cc = to_c_config(_cfg(**kw))
