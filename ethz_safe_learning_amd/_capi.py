@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-CEM_ABI_VERSION = 1
+CEM_ABI_VERSION = 2
 CEM_MAX_ACT = 32
 CEM_MAX_COST_KINDS = 4
 
@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     'cem_packed_weight_floats', 'cem_workspace_bytes', 'cem_pack_weights_host', 'cem_plan_tiles_host', 'cem_rollout_residency',
     'cem_planner_create', 'cem_planner_destroy', 'cem_planner_layout', 'cem_planner_set_weights',
     'cem_planner_set_normaliser', 'cem_planner_plan', 'cem_plan_begin', 'cem_plan_rollout', 'cem_plan_select',
-    'cem_plan_end', 'cem_unfold_sequences', 'cem_fill_noise', 'cem_planner_set_timing', 'cem_planner_last_timing',
+    'cem_plan_end', 'cem_unfold_sequences', 'cem_compute_objective', 'cem_scorer_reward', 'cem_scorer_cost', 'cem_fill_noise', 'cem_planner_set_timing', 'cem_planner_last_timing',
     'cem_trainer_workspace_bytes', 'cem_trainer_blob_floats', 'cem_trainer_create', 'cem_trainer_destroy', 'cem_trainer_set_state',
     'cem_trainer_get_state', 'cem_trainer_step', 'cem_trainer_eval',
 ]
@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
 class CemScorer(C.Structure):
     _fields_ = [
         ('goal_mode', C.c_int32), ('goal_lo', C.c_int32), ('goal_hi', C.c_int32),
-        ('lidar_max_dist', C.c_float), ('goal_size', C.c_float), ('reward_distance', C.c_float),
+        ('lidar_max_dist', C.c_float), ('goal_size', C.c_float), ('goal_reached_dist', C.c_float), ('reward_distance', C.c_float),
         ('reward_goal', C.c_float), ('reward_clip', C.c_float),
         ('constrain_indicator', C.c_int32), ('n_cost_kinds', C.c_int32),
         ('cost_lo', C.c_int32 * CEM_MAX_COST_KINDS), ('cost_hi', C.c_int32 * CEM_MAX_COST_KINDS),
@@ -108,6 +108,9 @@ def load():
     lib.cem_plan_select.argtypes = [vp, C.c_int32]
     lib.cem_plan_end.argtypes = [vp, vp, vp, fp, i32p]
     lib.cem_unfold_sequences.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, vp, C.c_uint64, C.c_uint64, vp, vp, vp]
+    lib.cem_compute_objective.argtypes = [vp, vp, C.c_int32, C.c_int32, vp]
+    lib.cem_scorer_reward.argtypes = [vp, vp, vp, C.c_int32, vp, vp]
+    lib.cem_scorer_cost.argtypes = [vp, vp, C.c_int32, vp]
     lib.cem_fill_noise.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, vp]
     lib.cem_planner_set_timing.argtypes = [vp, C.c_int32]
     lib.cem_planner_last_timing.argtypes = [vp, fp, i32p, fp]

@@ -42,6 +42,18 @@ int validate(const cem_config_t *c)
     // the select kernel keeps the elite list and two per-(step, action) arrays in dynamic LDS (140 KB available)
     if ((size_t)((c->n_elite + 3) & ~3) * 4 + (size_t)2 * c->horizon * c->act_dim * 4 > 140 * 1024) return CEM_ERR_UNSUPPORTED;
     if (c->scorer.n_cost_kinds < 0 || c->scorer.n_cost_kinds > CEM_MAX_COST_KINDS) return CEM_ERR_INVALID_ARG;
+    {   // scorer slices: inside the observation and non-empty (an empty lidar slice would make closest_distance +inf and rewards NaN)
+        const cem_scorer_t &s = c->scorer;
+        if (s.goal_mode != 0 && s.goal_mode != 1) return CEM_ERR_INVALID_ARG;
+        if (s.goal_lo < 0 || s.goal_lo >= c->obs_dim) return CEM_ERR_INVALID_ARG;
+        if (s.goal_mode == 0 && (s.goal_hi <= s.goal_lo || s.goal_hi > c->obs_dim)) return CEM_ERR_INVALID_ARG;
+        for (int k = 0; k < s.n_cost_kinds; ++k)
+            if (s.cost_lo[k] < 0 || s.cost_hi[k] <= s.cost_lo[k] || s.cost_hi[k] > c->obs_dim) return CEM_ERR_INVALID_ARG;
+        if (!(s.lidar_max_dist >= 0.f) || !(s.goal_reached_dist == s.goal_reached_dist)) return CEM_ERR_INVALID_ARG;
+    }
+    // flat int indices of the sample / rollout / reduce kernels: N*H*A and H*P*N/world must fit an int32
+    if ((long long)c->n_samples * c->horizon * ((c->act_dim + 3) & ~3) > 0x7fffffffll) return CEM_ERR_UNSUPPORTED;
+    if ((long long)c->particles * (c->n_samples / c->world_size) * c->horizon > 0x7fffffffll) return CEM_ERR_UNSUPPORTED;
     if (c->variant != CEM_VARIANT_CEM && c->variant != CEM_VARIANT_SAFE) return CEM_ERR_INVALID_ARG;
     if (c->chunks_per_tile < 0 || c->chunks_per_tile > 4) return CEM_ERR_INVALID_ARG;
     if ((long long)c->particles * c->n_samples > (1ll << 30)) return CEM_ERR_UNSUPPORTED;
@@ -169,6 +181,7 @@ void build_plan_tiles(const Dims &d, int rc, std::vector<Tile6> &out)
 // streamed weight group for more rows (less L2 traffic); smaller tiles pack the CUs more evenly and co-reside more easily.
 static const double kChunkSolo[2][4] = {{0.192, 0.168, 0.159, 0.157}, {1.25, 1.056, 1.010, 0.999}};
 static const double kChunkShared[2][4] = {{0.153, 0.148, 0.1445, 0.1445}, {1.00, 0.949, 0.93, 0.92}};
+#define CEM_MAX_DEVICES 64
 static const int kResidentStatic[2][4] = {{3, 2, 2, 2}, {2, 2, 1, 1}};     // from the kernels' VGPR counts (155/181/221/249, 206/240/274/335)
 
 template <int RC, int NFW>
@@ -186,8 +199,14 @@ int query_resident()
 // workgroups of the <rc, nfw> hot kernel one CU keeps resident: asked from the runtime, static table without a device
 int resident_workgroups(int nfw, int rc)
 {
-    static int cache[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};
-    int &c = cache[nfw - 1][rc - 1];
+    // per device: occupancy is a property of the kernel's code object on the CURRENT device
+    static int cache[CEM_MAX_DEVICES + 1][2][4];
+    static bool init = false;
+    if (!init) { for (auto &d : cache) for (auto &f : d) for (int &v : f) v = -1; init = true; }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = CEM_MAX_DEVICES; }     // no device: the static table's slot
+    if (dev < 0 || dev > CEM_MAX_DEVICES) dev = CEM_MAX_DEVICES;
+    int &c = cache[dev][nfw - 1][rc - 1];
     if (c < 0) {
         int n = 0;
 #define CEM_CASE(R, F) if (rc == R && nfw == F) n = query_resident<R, F>();
@@ -282,6 +301,9 @@ struct cem_planner {
     hipGraph_t graph; hipGraphExec_t gexec; bool graph_ready;
     ScorerDev sc;
     float alpha, beta;
+    size_t sel_dyn_limit;                    // dynamic-LDS allowance of the select kernels on this handle's device
+    // grow-only device scratch of the standalone ops (unfold_sequences tiles + returns, compute_objective returns + costs)
+    char *scratch; size_t scratch_bytes;
 };
 
 extern "C" {
@@ -383,15 +405,28 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
     h->timing = false; h->roll_ms = h->sel_ms = 0.f; h->roll_n = 0;
     h->graph = nullptr; h->gexec = nullptr; h->graph_ready = false;
     h->h_ctrl = nullptr; h->h_result = nullptr;
+    h->scratch = nullptr; h->scratch_bytes = 0;
+    // every failure from here on frees what was acquired and reports the HIP code
+    auto fail = [&](int status) {
+        g_last_hip = (int)hipGetLastError();
+        if (h->h_ctrl) hipHostFree(h->h_ctrl);
+        if (h->h_result) hipHostFree(h->h_result);
+        if (h->own_stream) hipStreamDestroy(h->stream);
+        delete h;
+        return status;
+    };
     if (hipHostMalloc((void **)&h->h_ctrl, sizeof(CtrlBlock), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void **)&h->h_result, 64 * 4, hipHostMallocDefault) != hipSuccess) { g_last_hip = (int)hipGetLastError(); delete h; return CEM_ERR_HIP; }
+        hipHostMalloc((void **)&h->h_result, 64 * 4, hipHostMallocDefault) != hipSuccess) return fail(CEM_ERR_HIP);
     std::memset(h->h_ctrl, 0, sizeof(CtrlBlock));
+    auto upload = [&](size_t off, const void *src, size_t bytes) {
+        return hipMemcpyAsync(h->ws + off, src, bytes, hipMemcpyHostToDevice, h->stream) == hipSuccess;
+    };
 
     // scorer constants, rounded the way the reference's Python-float -> fp32 tensor conversion rounds them
     const cem_scorer_t &s = cfg->scorer;
     ScorerDev &sc = h->sc;
     sc.goal_mode = s.goal_mode; sc.goal_lo = s.goal_lo; sc.goal_hi = s.goal_hi; sc.D = s.lidar_max_dist;
-    sc.goal_thresh = (float)((double)s.goal_size * 0.8);
+    sc.goal_thresh = s.goal_reached_dist;        // fl32(0.8 * goal_size) evaluated in double by the caller (safety_gym.py:116)
     sc.reward_distance = s.reward_distance; sc.reward_goal = s.reward_goal; sc.reward_clip = s.reward_clip;
     sc.indicator = s.constrain_indicator; sc.n_cost = s.n_cost_kinds;
     for (int i = 0; i < 4; ++i) { sc.cost_lo[i] = s.cost_lo[i]; sc.cost_hi[i] = s.cost_hi[i]; sc.cost_size[i] = s.cost_size[i]; }
@@ -401,32 +436,35 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
         h->alpha = alpha; h->beta = alpha * (1.0f / mu - 1.0f);
     }
 
-    // tiles -> device
+    // tiles, per-feature predicate tables of the rollout epilogue, identity normaliser (until set_normaliser) -> device
     std::vector<Tile6> tiles; build_plan_tiles(h->d, h->rc, tiles);
     h->n_tiles = (int)tiles.size();
-    if (hipMemcpyAsync(h->ws + h->lay.tiles, tiles.data(), tiles.size() * sizeof(Tile6), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
-        hipStreamSynchronize(h->stream) != hipSuccess) { g_last_hip = (int)hipGetLastError(); hipHostFree(h->h_ctrl); hipHostFree(h->h_result); delete h; return CEM_ERR_HIP; }
-    {   // per-feature predicate tables of the rollout epilogue
-        const Dims &d = h->d;
-        std::vector<float> om(2 * CEM_U, 0.f), ks(CEM_NKIND * CEM_U, std::numeric_limits<float>::infinity());
-        const float ninf = -std::numeric_limits<float>::infinity();
-        for (int f = 0; f < CEM_U; ++f) {
-            om[f] = f < d.O ? 1.f : 0.f;
-            om[CEM_U + f] = (f >= d.O && f < d.O + d.A) ? 1.f : 0.f;
-            const int ghi = s.goal_mode ? s.goal_lo + 1 : s.goal_hi;
-            if (f >= s.goal_lo && f < ghi && f < d.O) ks[f] = ninf;
-            for (int k = 0; k < s.n_cost_kinds; ++k)
-                if (f >= s.cost_lo[k] && f < s.cost_hi[k] && f < d.O) ks[(k + 1) * CEM_U + f] = ninf;
-        }
-        hipMemcpyAsync(h->ws + h->lay.omask, om.data(), om.size() * 4, hipMemcpyHostToDevice, h->stream);
-        hipMemcpyAsync(h->ws + h->lay.kind_sel, ks.data(), ks.size() * 4, hipMemcpyHostToDevice, h->stream);
-        hipStreamSynchronize(h->stream);
+    const Dims &d = h->d;
+    std::vector<float> om(2 * CEM_U, 0.f), ks(CEM_NKIND * CEM_U, std::numeric_limits<float>::infinity());
+    const float ninf = -std::numeric_limits<float>::infinity();
+    for (int f = 0; f < CEM_U; ++f) {
+        om[f] = f < d.O ? 1.f : 0.f;
+        om[CEM_U + f] = (f >= d.O && f < d.O + d.A) ? 1.f : 0.f;
+        const int ghi = s.goal_mode ? s.goal_lo + 1 : s.goal_hi;
+        if (f >= s.goal_lo && f < ghi && f < d.O) ks[f] = ninf;
+        for (int k = 0; k < s.n_cost_kinds; ++k)
+            if (f >= s.cost_lo[k] && f < s.cost_hi[k] && f < d.O) ks[(k + 1) * CEM_U + f] = ninf;
     }
-    // identity normaliser until set_normaliser is called
     std::vector<float> mn(CEM_U, 0.f), dl(CEM_U, 1.f);
-    hipMemcpyAsync(h->ws + h->lay.nmin, mn.data(), CEM_U * 4, hipMemcpyHostToDevice, h->stream);
-    hipMemcpyAsync(h->ws + h->lay.ndelta, dl.data(), CEM_U * 4, hipMemcpyHostToDevice, h->stream);
-    hipStreamSynchronize(h->stream);
+    if (!upload(h->lay.tiles, tiles.data(), tiles.size() * sizeof(Tile6)) || !upload(h->lay.omask, om.data(), om.size() * 4) ||
+        !upload(h->lay.kind_sel, ks.data(), ks.size() * 4) || !upload(h->lay.nmin, mn.data(), CEM_U * 4) ||
+        !upload(h->lay.ndelta, dl.data(), CEM_U * 4) || hipStreamSynchronize(h->stream) != hipSuccess)
+        return fail(CEM_ERR_HIP);
+
+    // Select kernel: scores staged in LDS when they fit.  gfx950 has 160 KB per CU and this kernel is the CU's only workgroup;
+    // beyond the default 64 KB per workgroup the runtime has to be asked, per device (19 KB of the budget are the kernel's
+    // static arrays).  Both variants: the uncached one still keeps the elite list (up to 24576 indices = 96 KB) in dynamic LDS.
+    h->sel_dyn_limit = 48 * 1024;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&cem_select_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            140 * 1024) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&cem_select_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            140 * 1024) == hipSuccess) h->sel_dyn_limit = 140 * 1024;
+    else (void)hipGetLastError();
     *out = h;
     return CEM_OK;
 }
@@ -434,6 +472,7 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
 int cem_planner_destroy(cem_planner_t *h)
 {
     if (!h) return CEM_ERR_INVALID_ARG;
+    if (h->scratch) hipFree(h->scratch);
     if (h->gexec) hipGraphExecDestroy(h->gexec);
     if (h->graph) hipGraphDestroy(h->graph);
     for (auto e : h->ev) hipEventDestroy(e);
@@ -594,19 +633,7 @@ int enqueue_select(cem_planner *h, int it)
     p.smoothing = h->cfg.smoothing; p.threshold = h->cfg.stddev_threshold;
     p.stamps = (long long *)(ws + l.stamps) + 64;          // past tile 0's rollout stamps; written by -DCEM_STAMPS builds only
     size_t lds = (size_t)((d.k + 3) & ~3) * 4 + (size_t)2 * d.H * d.A * 4;
-    // scores staged in LDS when they fit: gfx950 has 160 KB per CU and this kernel is the CU's only workgroup; beyond the
-    // default 64 KB per workgroup the runtime has to be asked once (19 KB of the budget are the kernel's static arrays).
-    // N = 16000 (the replicated select of an 8-GPU weak-scaled plan): 71 -> 57 us.
-    static size_t dyn_limit = 0;
-    if (!dyn_limit) {
-        dyn_limit = 48 * 1024;
-        // both variants: the uncached one still keeps the elite list (up to 24576 indices = 96 KB) in dynamic LDS
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&cem_select_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                140 * 1024) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&cem_select_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                140 * 1024) == hipSuccess) dyn_limit = 140 * 1024;
-        else (void)hipGetLastError();
-    }
+    const size_t dyn_limit = h->sel_dyn_limit;          // asked from the runtime at create(), per device
     const bool cache = lds + (size_t)d.N * 4 <= dyn_limit;
     if (cache) lds += (size_t)d.N * 4;
     size_t e0 = 0;
@@ -736,13 +763,37 @@ int cem_planner_plan(cem_planner_t *h, const float *state, uint64_t seed, uint64
     return cem_plan_end(h, eps_out_host, action_out, best_score_out, iters_out);
 }
 
+// grow-only device scratch of the standalone ops, cached on the handle (a hipMalloc / hipFree pair per call is a
+// device-wide synchronisation each)
+static int ensure_scratch(cem_planner *h, size_t bytes)
+{
+    if (bytes <= h->scratch_bytes) return CEM_OK;
+    if (h->scratch) { HIPCHK(hipStreamSynchronize(h->stream)); HIPCHK(hipFree(h->scratch)); h->scratch = nullptr; h->scratch_bytes = 0; }
+    const size_t want = align256(bytes + bytes / 2);
+    HIPCHK(hipMalloc((void **)&h->scratch, want));
+    h->scratch_bytes = want;
+    return CEM_OK;
+}
+
+// Philox key of a standalone call: only the 16-byte (seed, call) prefix of the device control block is written, and never
+// while a stepwise plan is in flight (its best-so-far / early-stop state and its own key live in the same block)
+static int upload_key(cem_planner *h, uint64_t seed, uint64_t call)
+{
+    CtrlBlock *c = h->h_ctrl;
+    c->seed_lo = (uint32_t)seed; c->seed_hi = (uint32_t)(seed >> 32); c->call_lo = (uint32_t)call; c->call_hi = (uint32_t)(call >> 32);
+    HIPCHK(hipMemcpyAsync(h->ws + h->lay.ctrl, c, 16, hipMemcpyHostToDevice, h->stream));
+    return CEM_OK;
+}
+
 int cem_unfold_sequences(cem_planner_t *h, const float *s0_dev, const float *actions_dev, int32_t n_rows, int32_t horizon,
                          const float *eps_model_dev, uint64_t seed, uint64_t call, float *traj_out_dev, float *mu_out_dev, float *sd_out_dev)
 {
     if (!h || !s0_dev || !actions_dev || n_rows < 1 || horizon < 1 || horizon > 65535) return CEM_ERR_INVALID_ARG;
     if (!h->have_weights) return CEM_ERR_NO_WEIGHTS;
+    if (h->in_plan) return CEM_ERR_STATE;
     const Dims &d = h->d;
     if (n_rows % d.E != 0) return CEM_ERR_SPLIT;
+    if ((long long)n_rows * (horizon + 1) * d.O > 0x7fffffff00ll) return CEM_ERR_UNSUPPORTED;
     const int chunk = n_rows / d.E;
     const int rc = n_rows >= 256 * 64 ? 4 : (n_rows >= 256 * 32 ? 2 : 1);
     std::vector<Tile6> tiles;
@@ -751,33 +802,73 @@ int cem_unfold_sequences(cem_planner_t *h, const float *s0_dev, const float *act
             Tile6 t; t.v[0] = r; t.v[1] = std::min(16 * rc, (m + 1) * chunk - r); t.v[2] = m; t.v[3] = r; t.v[4] = r; t.v[5] = r;
             tiles.push_back(t);
         }
-    TileDesc *dt = nullptr; float *ret = nullptr;
-    HIPCHK(hipMalloc((void **)&dt, tiles.size() * sizeof(Tile6)));
-    if (hipMalloc((void **)&ret, (size_t)n_rows * 4) != hipSuccess) { hipFree(dt); g_last_hip = (int)hipGetLastError(); return CEM_ERR_HIP; }
-    hipMemcpyAsync(dt, tiles.data(), tiles.size() * sizeof(Tile6), hipMemcpyHostToDevice, h->stream);
-    // Philox key for this call
-    CtrlBlock *c = h->h_ctrl;
-    c->seed_lo = (uint32_t)seed; c->seed_hi = (uint32_t)(seed >> 32); c->call_lo = (uint32_t)call; c->call_hi = (uint32_t)(call >> 32);
-    c->done = 0;
-    hipMemcpyAsync(h->ws + h->lay.ctrl, c, sizeof(CtrlBlock), hipMemcpyHostToDevice, h->stream);
+    const size_t tile_bytes = align256(tiles.size() * sizeof(Tile6));
+    int st = ensure_scratch(h, tile_bytes + (size_t)n_rows * 4); if (st) return st;
+    TileDesc *dt = (TileDesc *)h->scratch; float *ret = (float *)(h->scratch + tile_bytes);
+    // the tile list is pageable host memory: the copy has returned from it when hipMemcpyAsync returns only if it was staged;
+    // synchronise before `tiles` goes out of scope (below, with the kernel)
+    HIPCHK(hipMemcpyAsync(dt, tiles.data(), tiles.size() * sizeof(Tile6), hipMemcpyHostToDevice, h->stream));
+    st = upload_key(h, seed, call); if (st) return st;
     RolloutParams rp; fill_rollout_common(h, rp);
     rp.tiles = dt; rp.s0 = s0_dev; rp.actions = actions_dev; rp.eps_model = eps_model_dev; rp.ret = ret; rp.costs = nullptr;
     rp.traj = traj_out_dev; rp.mu_out = mu_out_dev; rp.sd_out = sd_out_dev;
     rp.H = horizon; rp.Bloc = n_rows; rp.Btot = n_rows; rp.it = 0; rp.variant = 0; rp.check_done = 0;
     hipError_t e = launch_rollout<1>(rc, d.NFW, rp, (int)tiles.size(), h->stream);
     hipError_t e2 = hipStreamSynchronize(h->stream);
-    hipFree(dt); hipFree(ret);
     HIPCHK(e); HIPCHK(e2);
     return CEM_OK;
+}
+
+int cem_compute_objective(cem_planner_t *h, const float *traj_dev, int32_t n_rows, int32_t horizon, float *scores_out_dev)
+{
+    if (!h || !traj_dev || !scores_out_dev || n_rows < 1 || horizon < 1 || horizon > 65535) return CEM_ERR_INVALID_ARG;
+    const Dims &d = h->d;
+    if (n_rows % d.P != 0) return CEM_ERR_INVALID_ARG;                 // reshape(cum, (particles, -1)) would raise (mpc_policy.py:38)
+    if ((long long)n_rows * horizon > 0x7fffffffll) return CEM_ERR_UNSUPPORTED;
+    const bool safe = h->cfg.variant == CEM_VARIANT_SAFE;
+    const size_t ret_bytes = align256((size_t)n_rows * 4);
+    int st = ensure_scratch(h, ret_bytes + (safe ? (size_t)n_rows * horizon : 0)); if (st) return st;
+    ObjectiveParams op{}; op.traj = traj_dev; op.ret = (float *)h->scratch; op.costs = safe ? (uint8_t *)(h->scratch + ret_bytes) : nullptr;
+    op.B = n_rows; op.H = horizon; op.O = d.O; op.variant = h->cfg.variant; op.sc = h->sc;
+    hipLaunchKernelGGL(cem_objective_kernel, dim3((unsigned)(((size_t)n_rows * 16 + 255) / 256)), dim3(256), 0, h->stream, op);
+    HIPCHK(hipGetLastError());
+    ReduceParams qp{}; qp.ret = op.ret; qp.costs = op.costs; qp.scores = scores_out_dev; qp.ctrl = (const CtrlBlock *)(h->ws + h->lay.ctrl);
+    qp.Nloc = n_rows / d.P; qp.P = d.P; qp.H = horizon; qp.variant = h->cfg.variant; qp.check_done = 0;
+    qp.alpha = h->alpha; qp.beta = h->beta; qp.thr = h->cfg.posterior_mean_threashold;
+    hipLaunchKernelGGL(cem_reduce_kernel, dim3((qp.Nloc + 63) / 64), dim3(CEM_REDUCE_THREADS), 0, h->stream, qp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CEM_OK;
+}
+
+static int scorer_op(cem_planner *h, const float *obs, const float *next_obs, int32_t n, float *out, uint8_t *flag, int what)
+{
+    ScorerOpParams sp{}; sp.obs = obs; sp.next_obs = next_obs; sp.out = out; sp.flag = flag; sp.n = n; sp.O = h->d.O; sp.what = what; sp.sc = h->sc;
+    hipLaunchKernelGGL(cem_scorer_kernel, dim3((unsigned)(((size_t)n * 16 + 255) / 256)), dim3(256), 0, h->stream, sp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CEM_OK;
+}
+
+int cem_scorer_reward(cem_planner_t *h, const float *obs_dev, const float *next_obs_dev, int32_t n, float *reward_out_dev,
+                      uint8_t *goal_achieved_out_dev)
+{
+    if (!h || !obs_dev || !next_obs_dev || !reward_out_dev || n < 1) return CEM_ERR_INVALID_ARG;
+    return scorer_op(h, obs_dev, next_obs_dev, n, reward_out_dev, goal_achieved_out_dev, 0);
+}
+
+int cem_scorer_cost(cem_planner_t *h, const float *obs_dev, int32_t n, float *cost_out_dev)
+{
+    if (!h || !obs_dev || !cost_out_dev || n < 1) return CEM_ERR_INVALID_ARG;
+    return scorer_op(h, obs_dev, nullptr, n, cost_out_dev, nullptr, 1);
 }
 
 int cem_fill_noise(cem_planner_t *h, uint64_t seed, uint64_t call, float *eps_act_dev, float *eps_model_dev, float *eps_out_dev)
 {
     if (!h) return CEM_ERR_INVALID_ARG;
+    if (h->in_plan) return CEM_ERR_STATE;
     const Dims &d = h->d;
-    CtrlBlock *c = h->h_ctrl;
-    c->seed_lo = (uint32_t)seed; c->seed_hi = (uint32_t)(seed >> 32); c->call_lo = (uint32_t)call; c->call_hi = (uint32_t)(call >> 32);
-    HIPCHK(hipMemcpyAsync(h->ws + h->lay.ctrl, c, sizeof(CtrlBlock), hipMemcpyHostToDevice, h->stream));
+    int st = upload_key(h, seed, call); if (st) return st;
     FillParams fp{}; fp.eps_act = eps_act_dev; fp.eps_model = eps_model_dev; fp.eps_out = eps_out_dev;
     fp.ctrl = (const CtrlBlock *)(h->ws + h->lay.ctrl); fp.I = d.I; fp.N = d.N; fp.H = d.H; fp.A = d.A; fp.B = d.Btot; fp.O = d.O;
     hipLaunchKernelGGL(cem_fill_noise_kernel, dim3(2048), dim3(256), 0, h->stream, fp);

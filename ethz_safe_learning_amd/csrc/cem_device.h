@@ -663,6 +663,108 @@ __global__ __launch_bounds__(CEM_REDUCE_THREADS) void cem_reduce_kernel(const Re
     p.scores[n] = score;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// the objective and the scorer as ops of their own, on tensors the caller holds (cem_compute_objective,
+// cem_scorer_reward, cem_scorer_cost).  HBM-bound: a group of 16 lanes owns one row and reads its features
+// 16 at a time (64-byte segments), min over the group with 4 shuffles; the arithmetic is the rollout epilogue's.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float cem_min16(float v)
+{
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 16));
+    return v;
+}
+
+// closest_distance over obs[lo:hi) (safety_gym.py:188-192): min over bins of clip(D - D*(1-x), 0, D)
+__device__ __forceinline__ float cem_closest16(const float *obs, int lo, int hi, float D, int j)
+{
+    float m = __builtin_inff();
+    for (int f = lo + j; f < hi; f += 16) m = fminf(m, fminf(fmaxf(D - D * (1.0f - obs[f]), 0.f), D));
+    return cem_min16(m);
+}
+
+__device__ __forceinline__ float cem_goal_dist16(const float *obs, const ScorerDev &sc, int j)
+{
+    if (sc.goal_mode) return fmaxf(obs[sc.goal_lo], 0.f);                       // squeeze(relu(goal_dist)), safety_gym.py:172-174
+    return cem_closest16(obs, sc.goal_lo, sc.goal_hi, sc.D, j);
+}
+
+__device__ __forceinline__ float cem_cost16(const float *obs, const ScorerDev &sc, int j)
+{
+    float c = 0.f;
+    for (int k = 0; k < sc.n_cost; ++k)                                          // safety_gym.py:148-163
+        c = c + ((cem_closest16(obs, sc.cost_lo[k], sc.cost_hi[k], sc.D, j) <= sc.cost_size[k]) ? 1.0f : 0.0f);
+    if (sc.indicator) c = c > 0.f ? 1.0f : 0.0f;                                 // :164-165
+    return c;
+}
+
+__device__ __forceinline__ float cem_reward_of(float d, float dn, bool ga, const ScorerDev &sc)
+{
+    float r = (d - dn) * sc.reward_distance + (ga ? 1.0f : 0.0f) * sc.reward_goal;   // safety_gym.py:117-119
+    if (sc.reward_clip > 0.f) r = fminf(fmaxf(r, -sc.reward_clip), sc.reward_clip);  // :140-142
+    return r;
+}
+
+struct ObjectiveParams {
+    const float *traj;           // [B][H+1][O]
+    float *ret;                  // [B]
+    uint8_t *costs;              // [H][B] (safe variant) or nullptr
+    int32_t B, H, O, variant;
+    ScorerDev sc;
+};
+
+__global__ __launch_bounds__(256) void cem_objective_kernel(const ObjectiveParams p)
+{
+    const int row = (int)((blockIdx.x * 256u + threadIdx.x) >> 4), j = threadIdx.x & 15;
+    if (row >= p.B) return;                                   // whole 16-lane groups leave together
+    const float *tr = p.traj + (size_t)row * (p.H + 1) * p.O;
+    float d_prev = cem_goal_dist16(tr, p.sc, j);
+    float c_prev = p.variant == 1 ? cem_cost16(tr, p.sc, j) : 0.f;
+    float cum = 0.f;
+    bool done = false;
+    for (int t = 0; t < p.H; ++t) {
+        const float *nx = tr + (size_t)(t + 1) * p.O;
+        const float dn = cem_goal_dist16(nx, p.sc, j);
+        const bool ga = d_prev <= p.sc.goal_thresh;                              // safety_gym.py:116
+        const float r = cem_reward_of(d_prev, dn, ga, p.sc);
+        if (p.variant == 1) {                                                    // safe_cem_mpc.py:86-93
+            done = done || ga;
+            const float nd = done ? 0.0f : 1.0f;
+            if (p.costs && j == 0) p.costs[(size_t)t * p.B + row] = (uint8_t)(c_prev * nd);
+            cum = cum + r * nd;
+            c_prev = cem_cost16(nx, p.sc, j);
+        } else {                                                                 // mpc_policy.py:34-37
+            const float nd = done ? 0.0f : 1.0f;
+            cum = cum + r * nd;
+            done = done || ga;
+        }
+        d_prev = dn;
+    }
+    if (j == 0) p.ret[row] = cum;
+}
+
+struct ScorerOpParams {
+    const float *obs, *next_obs; float *out; uint8_t *flag;
+    int32_t n, O, what;          // what 0: reward + goal_achieved, 1: cost
+    ScorerDev sc;
+};
+
+__global__ __launch_bounds__(256) void cem_scorer_kernel(const ScorerOpParams p)
+{
+    const int row = (int)((blockIdx.x * 256u + threadIdx.x) >> 4), j = threadIdx.x & 15;
+    if (row >= p.n) return;
+    const float *o = p.obs + (size_t)row * p.O;
+    if (p.what == 1) {
+        const float c = cem_cost16(o, p.sc, j);
+        if (j == 0) p.out[row] = c;
+        return;
+    }
+    const float d = cem_goal_dist16(o, p.sc, j), dn = cem_goal_dist16(p.next_obs + (size_t)row * p.O, p.sc, j);
+    const bool ga = d <= p.sc.goal_thresh;
+    const float r = cem_reward_of(d, dn, ga, p.sc);
+    if (j == 0) { p.out[row] = r; if (p.flag) p.flag[row] = ga ? 1 : 0; }
+}
+
 struct SelectParams {
     const float *scores; const float *actions; float *musig; CtrlBlock *ctrl; int32_t *elite_idx;
     int32_t N, k, HA, A, check_done;

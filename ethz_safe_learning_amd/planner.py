@@ -96,6 +96,8 @@ def to_c_config(cfg: PlannerConfig) -> _capi.CemConfig:
     c.scorer.goal_mode = 0 if s.observe_goal_lidar else 1
     c.scorer.goal_lo, c.scorer.goal_hi = int(s.goal_slice[0]), int(s.goal_slice[1])
     c.scorer.lidar_max_dist, c.scorer.goal_size = s.lidar_max_dist, s.goal_size
+    # goal_achieved = dist <= self.goal_size * 0.8 (safety_gym.py:116): a Python-float product converted to an fp32 tensor
+    c.scorer.goal_reached_dist = float(np.float32(float(s.goal_size) * 0.8))
     c.scorer.reward_distance, c.scorer.reward_goal = s.reward_distance, s.reward_goal
     c.scorer.reward_clip = float(s.reward_clip) if s.reward_clip else 0.0
     c.scorer.constrain_indicator = int(bool(s.constrain_indicator))
@@ -307,6 +309,46 @@ class CemPlanner:
         _capi.check(self.lib.cem_unfold_sequences(self.h, _ptr(s0), _ptr(actions), B, H, _ptr(em), seed, call,
                                                   _ptr(traj), _ptr(mu), _ptr(sd)), 'cem_unfold_sequences')
         return (traj, mu, sd) if return_moments else traj
+
+    def compute_objective(self, trajectories):
+        """MpcPolicy.compute_objective (mpc_policy.py:26-39) / SafeCemMpc.compute_objective (safe_cem_mpc.py:76-96) on a
+        given trajectory tensor [P*n, H+1, O] (rows in the tf.tile order p*n + candidate) -> scores [n] (torch, on the GPU)."""
+        t = self._torch
+        c = self.cfg
+        traj = t.as_tensor(trajectories, dtype=t.float32, device=self.device).contiguous()
+        if traj.dim() != 3 or traj.shape[2] != c.obs_dim or traj.shape[1] < 2:
+            raise ValueError('trajectories must be [P*n, H+1, obs_dim]')
+        B, H = traj.shape[0], traj.shape[1] - 1
+        if B % c.particles != 0:
+            raise ValueError('trajectory rows (%d) are not a multiple of particles (%d)' % (B, c.particles))
+        scores = t.empty((B // c.particles,), dtype=t.float32, device=self.device)
+        self._wait_inputs()
+        _capi.check(self.lib.cem_compute_objective(self.h, _ptr(traj), B, H, _ptr(scores)), 'cem_compute_objective')
+        return scores
+
+    def scorer_reward(self, observations, next_observations):
+        """SafetyGymStateScorer.reward (safety_gym.py:110-119,140-143): (reward [n] float32, goal_achieved [n] bool)."""
+        t = self._torch
+        obs = t.as_tensor(observations, dtype=t.float32, device=self.device).contiguous()
+        nxt = t.as_tensor(next_observations, dtype=t.float32, device=self.device).contiguous()
+        if obs.dim() != 2 or obs.shape[1] != self.cfg.obs_dim or nxt.shape != obs.shape:
+            raise ValueError('observations / next_observations must both be [n, obs_dim]')
+        r = t.empty((obs.shape[0],), dtype=t.float32, device=self.device)
+        g = t.empty((obs.shape[0],), dtype=t.uint8, device=self.device)
+        self._wait_inputs()
+        _capi.check(self.lib.cem_scorer_reward(self.h, _ptr(obs), _ptr(nxt), obs.shape[0], _ptr(r), _ptr(g)), 'cem_scorer_reward')
+        return r, g.bool()
+
+    def scorer_cost(self, observations):
+        """SafetyGymStateScorer.cost (safety_gym.py:145-166): cost [n] float32."""
+        t = self._torch
+        obs = t.as_tensor(observations, dtype=t.float32, device=self.device).contiguous()
+        if obs.dim() != 2 or obs.shape[1] != self.cfg.obs_dim:
+            raise ValueError('observations must be [n, obs_dim]')
+        c = t.empty((obs.shape[0],), dtype=t.float32, device=self.device)
+        self._wait_inputs()
+        _capi.check(self.lib.cem_scorer_cost(self.h, _ptr(obs), obs.shape[0], _ptr(c)), 'cem_scorer_cost')
+        return c
 
     def fill_noise(self, seed=0, call=0):
         """The Philox streams a (seed, call) plan consumes, as explicit tensors."""

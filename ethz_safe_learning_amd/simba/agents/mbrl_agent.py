@@ -6,10 +6,10 @@ import numpy as np
 from ..infrastructure.common import standardize_name
 from ..infrastructure.logging_utils import logger
 from ..models.transition_model import TransitionModel
-from ..policies import CemMpc, RandomMpc, SafeCemMpc            # noqa: F401  (resolved by name)
+from ..policies import CemMpc, RandomMpc, RandomShootingMpc, SafeCemMpc            # noqa: F401  (resolved by name)
 from .agent import BaseAgent
 
-_POLICIES = dict(CemMpc=CemMpc, SafeCemMpc=SafeCemMpc, RandomMpc=RandomMpc)
+_POLICIES = dict(CemMpc=CemMpc, SafeCemMpc=SafeCemMpc, RandomMpc=RandomMpc, RandomShootingMpc=RandomShootingMpc)
 
 
 class MbrlAgent(BaseAgent):

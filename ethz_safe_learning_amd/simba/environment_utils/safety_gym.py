@@ -2,7 +2,8 @@
 
 ``SafetyGymStateScorer`` keeps the reference's constructor (config dict copied onto attributes by setattr +
 sensor_offset_table, :104-108) and turns it into the parameter block of the fused reward/cost epilogue
-(``to_scorer_config``).  Its arithmetic (:110-192) runs inside cem_rollout_kernel, not here.
+(``to_scorer_config``).  Inside the planner its arithmetic (:110-192) is the epilogue of cem_rollout_kernel; ``reward`` /
+``cost`` as methods of their own run the same arithmetic through cem_scorer_reward / cem_scorer_cost (HIP; no host scorer).
 
 ``SyntheticSafetyGym`` stands in for ``MbrlSafetyGym`` (:9-101), whose MuJoCo / safety_gym simulator is not in this
 image: it provides the attributes the planner path reads — observation_space, action_space, sensor_offset_table,
@@ -52,11 +53,23 @@ class SafetyGymStateScorer(object):
                             reward_goal=float(self.reward_goal), reward_clip=float(self.reward_clip or 0.0),
                             constrain_indicator=bool(self.constrain_indicator), cost_kinds=kinds)
 
+    def _handle(self, device='cuda:0'):
+        """A planner handle that carries only this scorer (the scorer ops read nothing else from it)."""
+        from ...planner import PlannerConfig, cached_planner
+        obs_dim = max(self._bounds(sl)[1] for sl in self.sensor_offset_table.values())
+        cfg = PlannerConfig(obs_dim=obs_dim, act_dim=1, ensemble_size=1, particles=1, n_samples=1, horizon=1, n_elite=1,
+                            iterations=1, scorer=self.to_scorer_config(), act_low=[-1.0], act_high=[1.0])
+        return cached_planner(cfg, device=device)
+
     def reward(self, observations, next_observations):
-        raise NotImplementedError('fused into cem_rollout_kernel (csrc/cem_device.h); there is no host scorer')
+        """safety_gym.py:110-119,140-143 ('goal' task): (reward [n], goal_achieved [n]).  numpy in -> numpy out."""
+        r, g = self._handle().scorer_reward(observations, next_observations)
+        return (r.cpu().numpy(), g.cpu().numpy()) if isinstance(observations, np.ndarray) else (r, g)
 
     def cost(self, observations):
-        raise NotImplementedError('fused into cem_rollout_kernel (csrc/cem_device.h); there is no host scorer')
+        """safety_gym.py:145-166: cost [n]."""
+        c = self._handle().scorer_cost(observations)
+        return c.cpu().numpy() if isinstance(observations, np.ndarray) else c
 
 
 class SyntheticSafetyGym(object):

@@ -102,9 +102,16 @@ class MlpEnsemble(object):
         bounds = np.cumsum([0] + [len(a) for a in np.array_split(np.arange(n_train), n_batches)])             # np.array_split sizes, :174
         step = 0
         log_every = max(1, int(self.training_steps / 10))
+        # The host runs epochs ahead of the device (a step is ~0.2 ms, nothing here synchronises): every epoch's permutation
+        # tensor is read asynchronously by the steps queued on the trainer's stream, so it must not go back to torch's caching
+        # allocator (which only knows the stream it was allocated on) before those steps ran.  record_stream() tells the
+        # allocator about the trainer's stream; the list keeps the tensors alive until the final synchronize as well.
+        perms_alive = []
         while step < self.training_steps:
             shuffles_per_mlp = np.array([np.random.permutation(n_train) for _ in range(self.ensemble_size)])  # :172-173
             perm_dev = torch.from_numpy(shuffles_per_mlp.astype(np.int32)).to(dev)
+            perm_dev.record_stream(tr.stream)
+            perms_alive.append(perm_dev)
             for b in range(n_batches):
                 off, bt = int(bounds[b]), int(bounds[b + 1] - bounds[b])
                 tr.step(x_dev, y_dev, perm_dev, off, bt, self.learning_rate_at(tr.iterations), loss_dev[step])
@@ -116,6 +123,7 @@ class MlpEnsemble(object):
                 if step == self.training_steps:
                     break
         tr.synchronize()
+        del perms_alive
         losses = loss_dev.sum(dim=1).cpu().numpy().astype(np.float64)
         self._weights = tr.get_weights()
         self.version += 1

@@ -33,6 +33,8 @@ class TransitionModel(BaseModel):
         self.uid = next(_MODEL_UIDS)             # process-unique (id() is reused after garbage collection): keys staged weights
         self._planner = None
         self._planner_version = None
+        self.seed = 0
+        self._calls = 0                          # every unfold / predict without explicit noise draws fresh Philox noise
 
     @property
     def version(self):
@@ -82,10 +84,16 @@ class TransitionModel(BaseModel):
             self._planner_version = self.version
         return self._planner
 
-    def unfold_sequences(self, s_0, action_sequences, eps_model=None, seed=0, call=0):
+    def unfold_sequences(self, s_0, action_sequences, eps_model=None, seed=None, call=None):
         """transition_model.py:64-77: s_0 [B,O], actions [B,H,A] -> trajectories [B,H+1,O] (torch tensor on the GPU).
-        Row r is evaluated by member r // (B/E) (mlp_ensemble.py:123-126)."""
-        return self._get_planner().unfold_sequences(s_0, action_sequences, eps_model=eps_model, seed=seed, call=call)
+        Row r is evaluated by member r // (B/E) (mlp_ensemble.py:123-126).  Like the reference's Normal.sample()
+        (mlp_ensemble.py:189-193) every call draws fresh noise: the Philox stream is keyed on (self.seed, a per-model call
+        counter) unless ``seed`` / ``call`` (or the explicit ``eps_model`` tensor) pin it."""
+        if call is None:
+            call = self._calls
+            self._calls += 1
+        return self._get_planner().unfold_sequences(s_0, action_sequences, eps_model=eps_model,
+                                                    seed=self.seed if seed is None else seed, call=call)
 
     def simulate_trajectories(self, current_state, action_sequences, **kw):
         return self.unfold_sequences(current_state, action_sequences, **kw).cpu().numpy()      # :57-61

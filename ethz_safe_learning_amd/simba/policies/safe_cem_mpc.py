@@ -18,3 +18,6 @@ class SafeCemMpc(CemMpc):
 
     def _extra_config(self):
         return dict(posterior_mean_threashold=self.posterior_mean_threashold)
+
+    def _objective_extra_config(self):
+        return dict(posterior_mean_threashold=self.posterior_mean_threashold)

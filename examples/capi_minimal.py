@@ -30,6 +30,7 @@ def main(seed=0):
     sc = cfg.scorer                                                            # SafetyGymStateScorer, PointGoal1 layout
     sc.goal_mode, sc.goal_lo, sc.goal_hi = 0, 3, 19                            # goal lidar bins
     sc.lidar_max_dist, sc.goal_size, sc.reward_distance, sc.reward_goal, sc.reward_clip = 3.0, 0.3, 1.0, 1.0, 10.0
+    sc.goal_reached_dist = float(np.float32(0.3 * 0.8))                        # fl32 of the Python-float product (safety_gym.py:116)
     sc.constrain_indicator, sc.n_cost_kinds = 1, 1
     sc.cost_lo[0], sc.cost_hi[0], sc.cost_size[0] = 22, 38, 0.2                # hazards lidar bins
     cfg.world_size, cfg.rank, cfg.chunks_per_tile, cfg.use_graph = 1, 0, 0, 1

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CEM_ABI_VERSION 1
+#define CEM_ABI_VERSION 2
 #define CEM_MAX_ACT 32
 #define CEM_MAX_COST_KINDS 4
 
@@ -41,7 +41,7 @@ enum cem_status {
     CEM_ERR_WORKSPACE = 4,       /* workspace too small / misaligned */
     CEM_ERR_HIP = 5,             /* a HIP runtime call failed; cem_last_hip_error() has the code */
     CEM_ERR_NO_WEIGHTS = 6,      /* plan() before set_weights() */
-    CEM_ERR_STATE = 7            /* stepwise calls out of order */
+    CEM_ERR_STATE = 7            /* stepwise calls out of order, or a call that would clobber the state of a plan in flight */
 };
 
 enum cem_variant { CEM_VARIANT_CEM = 0 /* CemMpc */, CEM_VARIANT_SAFE = 1 /* SafeCemMpc */ };
@@ -54,6 +54,9 @@ typedef struct cem_scorer {
     int32_t goal_lo, goal_hi;     /* sensor_offset_table['goal_lidar'|'goal_dist'] */
     float lidar_max_dist;
     float goal_size;
+    float goal_reached_dist;      /* the threshold of `goal_achieved = dist <= 0.8 * goal_size` (safety_gym.py:116) as the reference
+                                   * rounds it: the Python-float product converted to an fp32 tensor, fl32(0.8 * goal_size) evaluated in
+                                   * double — NOT fl32(goal_size) * 0.8, which is 1 ulp higher at the default goal_size 0.3 */
     float reward_distance;
     float reward_goal;
     float reward_clip;            /* <= 0: no clip (safety_gym.py:141) */
@@ -162,6 +165,20 @@ int cem_plan_end(cem_planner_t *h, const float *eps_out_host, float *action_out,
 int cem_unfold_sequences(cem_planner_t *h, const float *s0_dev, const float *actions_dev, int32_t n_rows, int32_t horizon,
                          const float *eps_model_dev, uint64_t seed, uint64_t call,
                          float *traj_out_dev, float *mu_out_dev, float *sd_out_dev);
+
+/* MpcPolicy.compute_objective (mpc_policy.py:26-39) / SafeCemMpc.compute_objective (safe_cem_mpc.py:76-96) as an op of its
+ * own, on a GIVEN trajectory tensor: traj[n_rows][horizon+1][obs] (device), row r = p * (n_rows / particles) + candidate
+ * (the tf.tile order of cem_mpc.py:49-51) -> scores[n_rows / particles] (device).  Uses the handle's variant, particles,
+ * posterior threshold and scorer; `horizon` need not be the handle's.  The planner's own rollouts never call this (their
+ * objective is the rollout kernel's epilogue and the trajectory is never materialised); it serves callers that hold a
+ * trajectory tensor, e.g. from cem_unfold_sequences. */
+int cem_compute_objective(cem_planner_t *h, const float *traj_dev, int32_t n_rows, int32_t horizon, float *scores_out_dev);
+
+/* MbrlSafetyGym.get_reward / get_cost (safety_gym.py:62-66) -> SafetyGymStateScorer.reward / cost (:110-166), 'goal' task:
+ * obs[n][obs], next_obs[n][obs] (device) -> reward[n] (float), goal_achieved[n] (uint8; may be NULL); obs -> cost[n] (float). */
+int cem_scorer_reward(cem_planner_t *h, const float *obs_dev, const float *next_obs_dev, int32_t n, float *reward_out_dev,
+                      uint8_t *goal_achieved_out_dev);
+int cem_scorer_cost(cem_planner_t *h, const float *obs_dev, int32_t n, float *cost_out_dev);
 
 /* dump the Philox streams a (seed, call) plan consumes, in the explicit-tensor layouts above (device pointers; any may be NULL) */
 int cem_fill_noise(cem_planner_t *h, uint64_t seed, uint64_t call, float *eps_act_dev, float *eps_model_dev, float *eps_out_dev);

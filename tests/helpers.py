@@ -60,3 +60,56 @@ def elite_sets_equal_modulo_ties(scores, elite_a, elite_b, tol):
         return True
     kth = np.sort(scores)[::-1][len(a) - 1]
     return all(abs(float(scores[i]) - float(kth)) <= tol for i in a ^ b)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# scorer branches of SafetyGymStateScorer (safety_gym.py:145-176): several constrained kinds, the non-indicator sum,
+# observe_goal_dist instead of the goal lidar, no / active reward clip
+# --------------------------------------------------------------------------------------------------------------------
+# lidar-like slices per observation width: goal lidar, then the four cost kinds in the reference's order vases, hazards,
+# pillars, gremlins (safety_gym.py:148-163), and the feature used as goal_dist.  obs 60 (obs+act <= 64: one input block per
+# wave) reuses PointGoal1's layout and squeezes pillars / gremlins into the 3-wide gyro / velocimeter slots; obs 84 (two
+# input blocks per wave) has room for two more 8-bin lidars.
+SCORER_LAYOUTS = {
+    60: dict(goal=(3, 19), kinds=[(41, 57), (22, 38), (19, 22), (57, 60)], goal_dist=0),
+    84: dict(goal=(3, 19), kinds=[(41, 57), (22, 38), (64, 72), (72, 80)], goal_dist=60),
+}
+SCORER_SIZE_FRAC = 0.7
+SCORER_CASES = {
+    # name: (which of the four kinds are constrained, overrides)
+    'two_kinds': dict(kinds=[0, 1]),
+    'three_kinds': dict(kinds=[0, 1, 2]),
+    'four_kinds': dict(kinds=[0, 1, 2, 3]),
+    'four_kinds_sum': dict(kinds=[0, 1, 2, 3], constrain_indicator=False),
+    'one_kind_sum': dict(kinds=[1], constrain_indicator=False),
+    'no_cost_kinds': dict(kinds=[]),
+    'goal_dist': dict(kinds=[1], observe_goal_lidar=False),                                  # observe_goal_dist (safety_gym.py:172-174)
+    'goal_dist_sum3': dict(kinds=[0, 1, 2], observe_goal_lidar=False, constrain_indicator=False),
+    'no_reward_clip': dict(kinds=[1], reward_clip=0.0, reward_goal=25.0),                    # falsy clip: no clipping (safety_gym.py:141)
+    'active_reward_clip': dict(kinds=[1], reward_clip=0.02),                                 # |r| exceeds the clip on most steps
+}
+
+
+def scorer_problem(case, obs_dim=60, seed=31, E=5):
+    """A problem whose scorer exercises the named branch.  Lidar-like slices get lidar-like state values (closest distances
+    straddle the kinds' sizes) and the [0, 1] normaliser."""
+    spec, lay = SCORER_CASES[case], SCORER_LAYOUTS[obs_dim]
+    pb = make_problem(obs_dim, 2, E, 4, seed=seed)
+    rng = np.random.default_rng(seed + 5)
+    sp = pb['scorer']
+    for lo, hi in [lay['goal']] + lay['kinds']:
+        pb['state'][lo:hi] = rng.uniform(0.2, 0.9, hi - lo).astype(np.float32)
+        pb['inputs_min'][lo:hi] = 0.0
+        pb['inputs_max'][lo:hi] = 1.0
+    goal_lidar = spec.get('observe_goal_lidar', True)
+    goal_slice = lay['goal'] if goal_lidar else (lay['goal_dist'], lay['goal_dist'] + 1)
+    if not goal_lidar:
+        pb['state'][goal_slice[0]] = np.float32(0.27)          # goal_dist a little above 0.8 * goal_size: some rollouts reach the goal
+    # a kind's size sits just under the closest distance of the real s_0, so predicted states drift in and out of it
+    kinds = [(lay['kinds'][i][0], lay['kinds'][i][1],
+              float(np.float32(SCORER_SIZE_FRAC * sp.lidar_max_dist * pb['state'][lay['kinds'][i][0]:lay['kinds'][i][1]].min()))) for i in spec['kinds']]
+    pb['scorer'] = o.ScorerParams(goal_slice=goal_slice, observe_goal_lidar=goal_lidar,
+                                  lidar_max_dist=sp.lidar_max_dist, goal_size=sp.goal_size, reward_distance=sp.reward_distance,
+                                  reward_goal=spec.get('reward_goal', sp.reward_goal), reward_clip=spec.get('reward_clip', sp.reward_clip),
+                                  constrain_indicator=spec.get('constrain_indicator', True), cost_kinds=kinds)
+    return pb

@@ -51,6 +51,12 @@ def test_config_struct_matches_header_size(built_lib):
     (dict(n_elite=3000), 1),                             # k > N
     (dict(world_size=3), 1),                             # N % world != 0
     (dict(horizon=20000), 2),                            # elite list + 2 x H x A floats must fit the select kernel's LDS
+    (dict(scorer=ScorerConfig(goal_slice=(3, 61), cost_kinds=[(22, 38, 0.2)])), 1),          # goal slice runs past the observation
+    (dict(scorer=ScorerConfig(goal_slice=(19, 19), cost_kinds=[(22, 38, 0.2)])), 1),         # empty goal lidar: distance would be +inf
+    (dict(scorer=ScorerConfig(goal_slice=(3, 19), cost_kinds=[(38, 22, 0.2)])), 1),          # reversed cost slice
+    (dict(scorer=ScorerConfig(goal_slice=(3, 19), cost_kinds=[(-1, 8, 0.2)])), 1),
+    (dict(scorer=ScorerConfig(goal_slice=(60, 61), observe_goal_lidar=False)), 1),           # goal_dist feature outside the observation
+    (dict(n_samples=1 << 20, n_elite=16, horizon=600, particles=5), 2),                       # N*H*A would overflow the int32 index math
 ])
 def test_validation_errors(built_lib, kw, status):
     cc = to_c_config(_cfg(**kw))
@@ -60,7 +66,16 @@ def test_validation_errors(built_lib, kw, status):
     assert built_lib.cem_status_string(status)
 
 
+def test_goal_threshold_crosses_the_abi_rounded_once():
+    # fl32(0.3 * 0.8) evaluated in double = 0.23999999..., not fl32(0.3) * 0.8 = 0.24000001 (safety_gym.py:116)
+    cc = to_c_config(_cfg())
+    assert np.float32(cc.scorer.goal_reached_dist) == np.float32(0.3 * 0.8)
+    assert np.float32(cc.scorer.goal_reached_dist) < np.float32(np.float32(0.3) * np.float32(0.8))
+
+
 def test_null_handle_calls_fail_cleanly(built_lib):
+    assert built_lib.cem_compute_objective(None, None, 0, 0, None) == 1
+    assert built_lib.cem_scorer_cost(None, None, 0, None) == 1
     assert built_lib.cem_planner_destroy(None) == 1
     assert built_lib.cem_plan_rollout(None, 0) == 1
     assert built_lib.cem_planner_set_weights(None, None, 0) == 1

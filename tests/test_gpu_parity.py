@@ -1,9 +1,10 @@
 """Parity of the HIP path (through the C ABI) against the oracle on shared noise tensors.
 
 Tolerances (fp32 path, north-star: elite actions within 1e-5 rel):
-  * trajectories / head moments / per-row returns: |gpu - oracle64| <= 5e-5 absolute on O(1) quantities.  Both fp32
-    implementations (numpy's BLAS order and the MFMA's k-ordered fma chain) sit ~1e-6 from the fp64 shadow after H
-    recurrent steps; the bound leaves room for the amplification SURVEY section 7 warns about.
+  * trajectories / head moments / per-row returns: |gpu - oracle64| <= 5e-6 absolute on O(1) quantities (10x the
+    2-4.4e-7 measured on MI355X in round 1).  Both fp32 implementations (numpy's BLAS order and the MFMA's k-ordered fma
+    chain) sit a few 1e-7 from the fp64 shadow after H recurrent steps.  Scores near -100 (unsafe candidates of the
+    SafeCemMpc objective) get half an ulp of their magnitude on top (3.8e-6 at 100).
   * `<=` thresholds (goal reached, hazard hit) and top-k membership are discontinuous: rows/candidates whose fp64
     margin to a threshold is below 1e-4 are excluded from exact comparisons (and must be few).
   * sampled actions: bit-exact.  Selection given identical scores: bit-exact elite set, mu/sigma within 1e-6.
@@ -16,7 +17,13 @@ from tests import helpers as hp
 
 pytestmark = pytest.mark.gpu
 
-ATOL = 5e-5
+ATOL = 5e-6
+FULL_SIZE_ATOL = 2e-5        # bounded oracle subsets of the full-size BASELINE configs (H = 30-50 recurrent steps)
+
+
+def _score_err(scores, ref):
+    """max over candidates of |gpu - f64| in units of the allowance ATOL + half an fp32 ulp of |ref|."""
+    return (np.abs(scores - ref) / (ATOL + 6e-8 * np.abs(ref))).max()
 
 
 def _torch():
@@ -118,9 +125,90 @@ def test_rollout_scores_match_oracle(variant, P, E, N, H, post):
     assert ok.mean() > 0.9, 'too many candidates on a threshold for a meaningful test'
     err = np.abs(scores - ref64)[ok].max()
     print('%s scores: max|gpu-f64| = %.3g over %d/%d candidates' % (variant, err, ok.sum(), N))
-    assert err <= ATOL
+    assert _score_err(scores[ok], ref64[ok]) <= 1.0
     if variant == 'safe':
         assert (ref64 < -50).any() and (ref64 > -50).any(), 'test should see both safe and unsafe candidates'
+
+
+@pytest.mark.parametrize('obs_dim', [60, 84])
+@pytest.mark.parametrize('variant', ['cem', 'safe'])
+@pytest.mark.parametrize('case', list(hp.SCORER_CASES))
+def test_rollout_scorer_branches(case, variant, obs_dim):
+    """Every branch of SafetyGymStateScorer the 'goal' task can take (safety_gym.py:145-176), on the HIP path against the
+    fp64 oracle: 0-4 constrained kinds (vases + hazards + pillars + gremlins summed), constrain_indicator on / off,
+    observe_goal_dist instead of the goal lidar, reward clip absent / active — in both kernel families (obs+act <= 64 and
+    > 64) and both objectives.  For SafeCemMpc the per-step done-masked costs (safe_cem_mpc.py:89) are compared too."""
+    torch = _torch()
+    pb = hp.scorer_problem(case, obs_dim)
+    N, H, P, E = 96, 8, 5, 5
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=9, I=1, variant=variant, post=0.5)
+    pl = hp.make_planner(pb, pcfg)
+    ea, em, eo = hp.noise(1, N, H, 2, P, obs_dim, seed=8)
+    actions, returns, scores = _run_iteration(pl, pb, ocfg, ea, em)
+    lb, ub, mu0, sg0 = o.sampling_params(pb['low'], pb['high'])
+    ref_actions = o.sample_actions(np.broadcast_to(mu0, (H, 2)), np.broadcast_to(sg0, (H, 2)), lb, ub, ea[0])
+    np.testing.assert_array_equal(actions, ref_actions)
+    w64 = o.cast_weights(pb['weights'], np.float64)
+    ref64, traj64 = o.candidate_scores(pb['state'].astype(np.float64), ref_actions.astype(np.float64), w64, pb['inputs_min'],
+                                       pb['inputs_max'], em[0], ocfg, pb['scorer'], return_traj=True)
+    row_ok = o.threshold_margins(traj64, pb['scorer']) > 1e-4
+    ok = row_ok.reshape(P, N).all(axis=0)
+    assert ok.mean() > 0.8, 'too many candidates on a threshold for a meaningful test'
+    err = np.abs(scores - ref64)[ok].max()
+    print('%s obs %d %s: max|gpu-f64| = %.3g over %d/%d candidates' % (case, obs_dim, variant, err, ok.sum(), N))
+    assert _score_err(scores[ok], ref64[ok]) <= 1.0
+    sp = pb['scorer']
+    if variant == 'safe':
+        # the masked per-step cost of every row, exactly (small integers): done OR-ed first, then cost(s_t) * (1 - done)
+        done = np.zeros(P * N, bool)
+        ref_costs = np.zeros((H, P * N))
+        for t in range(H):
+            _, d = o.reward(traj64[:, t], traj64[:, t + 1], sp)
+            done |= d
+            ref_costs[t] = o.cost(traj64[:, t], sp) * (1.0 - done)
+        gpu_costs = pl.costs().cpu().numpy().reshape(H, P * N).astype(np.float64)
+        np.testing.assert_array_equal(gpu_costs[:, row_ok], ref_costs[:, row_ok])
+        if sp.cost_kinds:
+            assert ref_costs.max() >= 1 and (ref_costs == 0).any()
+            if not sp.constrain_indicator and len(sp.cost_kinds) > 1:
+                assert ref_costs.max() >= 2, 'the non-indicator sum should exceed 1 somewhere'
+    if case == 'active_reward_clip':
+        r, _ = o.reward(traj64[:, 0], traj64[:, 1], sp)
+        assert (np.abs(r) == sp.reward_clip).mean() > 0.3
+    if not sp.observe_goal_lidar:
+        assert any(o.reward(traj64[:, t], traj64[:, t + 1], sp)[1].any() for t in range(H)), 'goal_dist case should reach the goal'
+
+
+def test_normaliser_degenerate_columns():
+    """TransitionModel.scale (transition_model.py:84-85): a column whose max - min < 1e-5 is divided by 1.01 instead.
+    cem_planner_set_normaliser applies that rule on the host; one observation and one action column are degenerate here."""
+    torch = _torch()
+    pb = hp.make_problem(seed=33)
+    pb['inputs_max'][7] = pb['inputs_min'][7] + np.float32(5e-6)       # below the 1e-5 threshold
+    pb['inputs_max'][25] = pb['inputs_min'][25]                        # exactly zero range
+    pb['inputs_min'][61] = pb['inputs_max'][61] = np.float32(0.25)     # an action column
+    pb['inputs_max'][30] = pb['inputs_min'][30] + np.float32(2e-5)     # just above: a genuinely tiny delta (x 5e4)
+    N, H, P, E = 80, 6, 5, 5
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=8, I=1)
+    pl = hp.make_planner(pb, pcfg)
+    ea, em, eo = hp.noise(1, N, H, 2, P, 60, seed=8)
+    actions, returns, scores = _run_iteration(pl, pb, ocfg, ea, em)
+    w64 = o.cast_weights(pb['weights'], np.float64)
+    ref64, traj64 = o.candidate_scores(pb['state'].astype(np.float64), actions.astype(np.float64), w64, pb['inputs_min'],
+                                       pb['inputs_max'], em[0], ocfg, pb['scorer'], return_traj=True)
+    ok = o.threshold_margins(traj64, pb['scorer']).reshape(P, N).min(axis=0) > 1e-4
+    assert ok.mean() > 0.8
+    # the x 5e4 column amplifies rounding of (x - min): compare against the fp32 oracle as well and allow its own distance
+    ref32 = o.candidate_scores(pb['state'], actions, pb['weights'], pb['inputs_min'], pb['inputs_max'], em[0], ocfg, pb['scorer'])
+    scale32 = max(1.0, np.abs(ref32 - ref64)[ok].max() / 4.4e-7)
+    err = np.abs(scores - ref64)[ok].max()
+    print('degenerate normaliser: max|gpu-f64| = %.3g (numpy32-f64 %.3g)' % (err, np.abs(ref32 - ref64)[ok].max()))
+    assert err <= ATOL * scale32
+    # and the rule itself, not just agreement: the degenerate columns really were divided by 1.01
+    x = np.concatenate([pb['state'], actions[0, 0]])[None, :].astype(np.float64)
+    xs = o.scale(x, pb['inputs_min'], pb['inputs_max'])
+    np.testing.assert_allclose(xs[0, 7], (x[0, 7] - pb['inputs_min'][7]) / 1.01)
+    np.testing.assert_allclose(xs[0, 61], (x[0, 61] - 0.25) / 1.01)
 
 
 @pytest.mark.parametrize('seed', range(12))
@@ -151,7 +239,7 @@ def test_rollout_scores_random_shapes(seed):
     err = np.abs(scores - ref64)[ok].max()
     print('seed %d: O=%d A=%d E=%d P=%d N=%d H=%d %s rc=%d sampling=%s scale=%s: max|gpu-f64| = %.3g over %d/%d'
           % (seed, O, A, E, P, N, H, variant, rc, sampling, scale, err, ok.sum(), N))
-    assert err <= ATOL
+    assert _score_err(scores[ok], ref64[ok]) <= 1.0
 
 
 def test_select_is_exact_on_given_scores():
@@ -217,7 +305,7 @@ def test_select_edge_cases(case):
     mean, var = o.moments(actions[o.top_k(sc, k)])
     ms = pl.mu_sigma().cpu().numpy()
     np.testing.assert_allclose(ms[0], mean, rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(ms[1], np.sqrt(var), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(ms[1], np.sqrt(var), rtol=2e-5, atol=1e-6)
 
 
 def test_select_wide_moments_path_matches_oracle():
@@ -270,13 +358,15 @@ def test_full_plan_matches_oracle(variant):
         scores = pl.scores_local().cpu().numpy().copy()
         if elites_match:
             np.testing.assert_allclose(pl.actions().cpu().numpy(), trace[it]['actions'], rtol=1e-5, atol=1e-6)
-            bad = np.abs(scores - trace[it]['scores']) > 1e-4
+            # the trace is the fp32 numpy oracle: both sides sit a few 1e-7 from fp64; a row that crosses a `<=` threshold
+            # on one side only moves by a whole reward / cost unit, and such rows must be rare
+            bad = np.abs(scores - trace[it]['scores']) > FULL_SIZE_ATOL
             assert bad.mean() < 0.05, 'iteration %d: %d/%d scores differ' % (it, bad.sum(), N)
         pl.plan_select(it)
         torch.cuda.synchronize()
         elite = pl.elite_idx().cpu().numpy()
         if elites_match and set(elite.tolist()) != set(trace[it]['elite'].tolist()):
-            assert hp.elite_sets_equal_modulo_ties(trace[it]['scores'], elite, trace[it]['elite'], 1e-4)
+            assert hp.elite_sets_equal_modulo_ties(trace[it]['scores'], elite, trace[it]['elite'], FULL_SIZE_ATOL)
             elites_match = False          # a near-tie flipped: later iterations legitimately diverge
         if elites_match:
             ms = pl.mu_sigma().cpu().numpy()
@@ -284,9 +374,10 @@ def test_full_plan_matches_oracle(variant):
             np.testing.assert_allclose(ms[1], trace[it]['sigma'], rtol=1e-5, atol=1e-6)
     a, s, it = pl.plan_end(eps_out=eo)
     assert it == rit == I
-    if elites_match:
-        np.testing.assert_allclose(a, ra, rtol=1e-5, atol=1e-7)
-        assert abs(s - rs) <= 1e-4
+    # fixed seeds: no near-tie sits on the elite boundary here, so the final action is ALWAYS compared (north-star: 1e-5 rel)
+    assert elites_match, 'an elite set differed from the oracle (a near-tie on the k-th score?)'
+    np.testing.assert_allclose(a, ra, rtol=1e-5, atol=1e-7)
+    assert abs(s - rs) <= FULL_SIZE_ATOL
     print('%s plan: elite sets matched in every iteration: %s' % (variant, elites_match))
 
 
@@ -304,7 +395,7 @@ def test_plan_philox_equals_plan_on_dumped_noise_and_graph():
     # and the oracle agrees on that dumped noise
     ra, rs, rit = o.do_generate_action(pb['state'], pb['weights'], pb['inputs_min'], pb['inputs_max'], pb['low'], pb['high'],
                                        ea.cpu().numpy(), em.cpu().numpy(), eo.cpu().numpy(), ocfg, pb['scorer'])
-    assert abs(s1 - rs) <= 1e-4
+    assert abs(s1 - rs) <= FULL_SIZE_ATOL
     # the hipGraph-captured plan is the same computation
     _, gcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, noise=0.05, use_graph=True)
     pg = hp.make_planner(pb, gcfg)
@@ -370,7 +461,7 @@ def test_b2_full_size_properties():
     def scores_of(planner):
         planner.plan_begin(pb['state'], seed=3, call=1)
         planner.plan_rollout(0)
-        torch.cuda.synchronize()
+        planner.plan_end()
         return planner.scores_local().cpu().numpy().copy()
     s_a = scores_of(pl)
     s_b = scores_of(pl)
@@ -395,7 +486,9 @@ def test_b2_full_size_properties():
                                    members=o.member_of_rows(P * N, E, rows), return_traj=True)
     ok = o.threshold_margins(traj, pb['scorer']).reshape(P, sub).min(axis=0) > 1e-4
     assert ok.sum() > sub // 2
-    assert np.abs(s_a[:sub] - ref)[ok].max() <= 2e-4
+    err = np.abs(s_a[:sub] - ref)[ok].max()
+    print('B2: max|gpu-f64| over %d bounded candidates = %.3g' % (ok.sum(), err))
+    assert err <= FULL_SIZE_ATOL
 
 
 # ------------------------------------------------------------------------------------------------- BASELINE configs
@@ -423,19 +516,19 @@ def test_b1_reference_scale_plan_matches_oracle():
         torch.cuda.synchronize()
         sc = pl.scores_local().cpu().numpy().copy()
         if match:
-            bad = np.abs(sc - trace[it]['scores']) > 1e-4
+            bad = np.abs(sc - trace[it]['scores']) > FULL_SIZE_ATOL
             assert bad.mean() < 0.03, 'iteration %d: %d/%d scores differ' % (it, bad.sum(), N)
         pl.plan_select(it)
         torch.cuda.synchronize()
         el = pl.elite_idx().cpu().numpy()
         if match and set(el.tolist()) != set(trace[it]['elite'].tolist()):
-            assert hp.elite_sets_equal_modulo_ties(trace[it]['scores'], el, trace[it]['elite'], 1e-4)
+            assert hp.elite_sets_equal_modulo_ties(trace[it]['scores'], el, trace[it]['elite'], FULL_SIZE_ATOL)
             match = False
     a, s, it = pl.plan_end(eps_out=eo)
     assert it == rit
-    if match:
-        np.testing.assert_allclose(a, ra, rtol=1e-5, atol=1e-7)
-        assert abs(s - rs) <= 1e-4
+    assert match, 'an elite set differed from the oracle (a near-tie on the k-th score?)'
+    np.testing.assert_allclose(a, ra, rtol=1e-5, atol=1e-7)
+    assert abs(s - rs) <= FULL_SIZE_ATOL
     print('B1 plan: elite sets matched in every iteration: %s' % match)
 
 
@@ -456,7 +549,7 @@ def test_large_baseline_configs_properties(name, O, A, K, N, H):
         planner.plan_rollout(0)
         if select:
             planner.plan_select(0)
-        torch.cuda.synchronize()
+        planner.plan_end()
         return planner.scores_local().cpu().numpy().copy()
     s1 = scores_of(pl, select=True)
     elite = np.sort(pl.elite_idx().cpu().numpy())
@@ -465,7 +558,7 @@ def test_large_baseline_configs_properties(name, O, A, K, N, H):
     mean, var = o.moments(acts[elite])
     ms = pl.mu_sigma().cpu().numpy()
     np.testing.assert_allclose(ms[0], mean, rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(ms[1], np.sqrt(var), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(ms[1], np.sqrt(var), rtol=2e-5, atol=1e-6)
     np.testing.assert_array_equal(scores_of(pl), s1)
     assert np.isfinite(s1).all() and s1.std() > 1e-3
     halves = []
@@ -490,4 +583,179 @@ def test_large_baseline_configs_properties(name, O, A, K, N, H):
     assert ok.sum() > sub // 2
     err = np.abs(s1[:sub] - ref)[ok].max()
     print('%s: max|gpu-f64| over %d bounded candidates = %.3g' % (name, ok.sum(), err))
-    assert err <= 5e-4
+    assert err <= FULL_SIZE_ATOL
+
+
+def test_b5_sharded_population_on_one_gpu():
+    """BASELINE config B5 (N = 65536 candidates over 8 GPUs, K = P = E = 5, H = 30, k = N/10 = 6554) exercised on ONE GPU:
+    (a) the single-rank rollout scores (327680 rows) equal the concatenation of the eight world_size-8 rank shards bit for bit;
+    (b) the replicated select every B5 rank runs — 65536 scores do not fit the LDS cache, k = 6554 elites — is exact against
+        tf.nn.top_k / tf.nn.moments semantics on the GPU's own scores;
+    (c) a bounded oracle check on the first 32 candidates at full width."""
+    torch = _torch()
+    pb = _baseline_problem(60, 2, 5, 2468)
+    N, H, P, E, I = 65536, 30, 5, 5, 1
+    k = 6554
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I)
+    pl = hp.make_planner(pb, pcfg)
+
+    def scores_of(planner):
+        planner.plan_begin(pb['state'], seed=9, call=4)
+        planner.plan_rollout(0)
+        torch.cuda.synchronize()
+        return planner.scores_local().cpu().numpy().copy()
+    s1 = scores_of(pl)
+    assert s1.shape == (N,) and np.isfinite(s1).all() and s1.std() > 1e-3
+    acts = pl.actions().cpu().numpy().copy()
+    # (a) eight rank shards, each with its own handle (tiles, Philox rows and members keyed on GLOBAL indices)
+    shards = []
+    for r in range(8):
+        _, c8 = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, world_size=8, rank=r)
+        p8 = hp.make_planner(pb, c8)
+        shards.append(scores_of(p8))
+        if r == 3:
+            np.testing.assert_array_equal(p8.actions().cpu().numpy(), acts)      # every rank samples all N sequences identically
+        p8.close()
+    np.testing.assert_array_equal(np.concatenate(shards), s1)
+    # (b) the select of a B5 rank on the full score vector
+    pl.plan_select(0)
+    torch.cuda.synchronize()
+    elite = np.sort(pl.elite_idx().cpu().numpy())
+    ref_elite = o.top_k(s1, k)
+    np.testing.assert_array_equal(elite, ref_elite)
+    mean, var = o.moments(acts[ref_elite])
+    ms = pl.mu_sigma().cpu().numpy()
+    np.testing.assert_allclose(ms[0], mean, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ms[1], np.sqrt(var), rtol=2e-5, atol=1e-6)
+    a, sc, it = pl.plan_end(eps_out=np.zeros(2, np.float32))
+    j = o.best_of_elite(s1, ref_elite)
+    assert sc == s1[j] and it == 1
+    np.testing.assert_array_equal(a, acts[j, 0])
+    # (c) bounded oracle check: the first 32 candidates on the dumped noise
+    ea, em, eo = pl.fill_noise(seed=9, call=4)
+    sub = 32
+    rows = np.concatenate([p * N + np.arange(sub) for p in range(P)])
+    lb, ub, mu0, sg0 = o.sampling_params(pb['low'], pb['high'])
+    a0 = o.sample_actions(np.broadcast_to(mu0, (H, 2)), np.broadcast_to(sg0, (H, 2)), lb, ub, ea[0, :sub].cpu().numpy())
+    np.testing.assert_array_equal(a0, acts[:sub])
+    em_sub = em[0][:, torch.as_tensor(rows, device=em.device)].cpu().numpy()
+    del ea, em
+    ref, traj = o.candidate_scores(pb['state'].astype(np.float64), a0.astype(np.float64), o.cast_weights(pb['weights'], np.float64),
+                                   pb['inputs_min'], pb['inputs_max'], em_sub, ocfg, pb['scorer'],
+                                   members=o.member_of_rows(P * N, E, rows), return_traj=True)
+    ok = o.threshold_margins(traj, pb['scorer']).reshape(P, sub).min(axis=0) > 1e-4
+    assert ok.sum() > sub // 2
+    err = np.abs(s1[:sub] - ref)[ok].max()
+    print('B5: max|gpu-f64| over %d bounded candidates = %.3g' % (ok.sum(), err))
+    assert err <= FULL_SIZE_ATOL
+
+
+# ------------------------------------------------------------------------------------------------- standalone ops
+@pytest.mark.parametrize('variant', ['cem', 'safe'])
+@pytest.mark.parametrize('case', ['default', 'four_kinds_sum', 'goal_dist', 'active_reward_clip'])
+def test_compute_objective_op_matches_oracle(case, variant):
+    """cem_compute_objective = MpcPolicy.compute_objective (mpc_policy.py:26-39) / SafeCemMpc.compute_objective
+    (safe_cem_mpc.py:76-96) on a GIVEN trajectory tensor, against the oracle on the same tensor — and against the fused
+    epilogue of the rollout kernel on the trajectory that kernel itself wrote (bit for bit)."""
+    torch = _torch()
+    pb = hp.make_problem(seed=31) if case == 'default' else hp.scorer_problem(case, 60)
+    N, H, P, E = 80, 9, 5, 5
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=8, I=1, variant=variant, post=0.5)
+    pl = hp.make_planner(pb, pcfg)
+    ea, em, eo = hp.noise(1, N, H, 2, P, 60, seed=8)
+    actions, returns, scores = _run_iteration(pl, pb, ocfg, ea, em)
+    pl.plan_end()
+    # the trajectory of the same rows from the debug instantiation of the rollout kernel
+    s0 = np.broadcast_to(pb['state'], (P * N, 60)).copy()
+    a_b = np.tile(actions, (P, 1, 1))
+    traj = pl.unfold_sequences(s0, a_b, eps_model=em[0])
+    got = pl.compute_objective(traj).cpu().numpy()
+    np.testing.assert_array_equal(got, scores)                 # standalone op == fused epilogue, same fp32 trajectory
+    t64 = traj.cpu().numpy().astype(np.float64)
+    if variant == 'safe':
+        ref = o.compute_objective_safe(t64, P, N, pb['scorer'], 0.5)
+    else:
+        ref = o.compute_objective_cem(t64, P, N, pb['scorer'])
+    ok = o.threshold_margins(t64, pb['scorer']).reshape(P, N).min(axis=0) > 1e-5
+    assert ok.mean() > 0.8
+    assert _score_err(got[ok], ref[ok]) <= 1.0
+    # a horizon other than the handle's and numpy in / numpy out through the policy-level wrapper are covered in test_simba_api
+
+
+def test_scorer_ops_match_oracle():
+    """cem_scorer_reward / cem_scorer_cost = env.get_reward / get_cost (safety_gym.py:62-66,110-166) on arbitrary observation
+    batches: rewards to fp32 rounding, goal flags and costs exactly (rows within 1e-5 of a threshold excluded)."""
+    torch = _torch()
+    rng = np.random.default_rng(3)
+    for case in ('four_kinds_sum', 'goal_dist', 'no_reward_clip', 'active_reward_clip', 'two_kinds'):
+        pb = hp.scorer_problem(case, 84)
+        _, pcfg = hp.configs(pb, N=5, H=1, P=5, E=5, k=1, I=1)
+        pl = hp.make_planner(pb, pcfg)
+        n = 1000 + 7
+        obs = rng.uniform(-0.2, 1.1, (n, 84)).astype(np.float32)
+        nxt = (obs + rng.normal(0, 0.05, (n, 84))).astype(np.float32)
+        obs[:5] = nxt[:5] = 0.0
+        sp = pb['scorer']
+        r, g = pl.scorer_reward(obs, nxt)
+        c = pl.scorer_cost(obs)
+        r, g, c = r.cpu().numpy(), g.cpu().numpy(), c.cpu().numpy()
+        rr, gg = o.reward(obs.astype(np.float64), nxt.astype(np.float64), sp)
+        cc = o.cost(obs.astype(np.float64), sp)
+        m = o.threshold_margins(obs[:, None, :].astype(np.float64), sp)
+        ok = m > 1e-5
+        assert ok.mean() > 0.9
+        np.testing.assert_array_equal(g[ok], gg[ok])
+        np.testing.assert_array_equal(c[ok], cc[ok])
+        np.testing.assert_allclose(r[ok], rr[ok], rtol=0, atol=2e-6)
+        # fp32 oracle: identical op for op
+        r32, g32 = o.reward(obs, nxt, sp)
+        np.testing.assert_array_equal(r[ok], r32[ok])
+        pl.close()
+
+
+def test_goal_threshold_is_rounded_once():
+    """goal_achieved = dist <= fl32(0.8 * goal_size) with the product evaluated in double (safety_gym.py:116): at the default
+    goal_size 0.3 that is 0.23999999; fl32(0.3) * 0.8 would be 0.24000001, one ulp higher.  A goal distance of exactly the
+    float above 0.23999999 must NOT count as reached."""
+    torch = _torch()
+    pb = hp.scorer_problem('goal_dist', 60)
+    thr = np.float32(0.3 * 0.8)
+    above = np.nextafter(thr, np.float32(1.0))
+    assert np.float32(np.float32(0.3) * np.float32(0.8)) >= above       # the double-rounded value this test guards against
+    _, pcfg = hp.configs(pb, N=5, H=1, P=5, E=5, k=1, I=1)
+    pl = hp.make_planner(pb, pcfg)
+    g0 = pb['scorer'].goal_slice[0]
+    obs = np.tile(pb['state'], (3, 1)).astype(np.float32)
+    obs[0, g0], obs[1, g0], obs[2, g0] = thr, above, np.nextafter(thr, np.float32(0.0))
+    r, g = pl.scorer_reward(obs, obs)
+    np.testing.assert_array_equal(g.cpu().numpy(), [True, False, True])
+    np.testing.assert_array_equal(r.cpu().numpy(), np.array([1.0, 0.0, 1.0], np.float32) * np.float32(pb['scorer'].reward_goal))
+    # and inside the fused rollout: a state sitting exactly one ulp above the threshold earns no goal bonus at step 0
+    st = pb['state'].copy(); st[g0] = above
+    ocfg, pcfg = hp.configs(pb, N=16, H=1, P=5, E=5, k=2, I=1)
+    pl2 = hp.make_planner(pb, pcfg)
+    ea, em, eo = hp.noise(1, 16, 1, 2, 5, 60, seed=1)
+    pl2.plan_begin(st, eps_act=ea, eps_model=em); pl2.plan_rollout(0); pl2.plan_end()
+    ret = pl2.returns().cpu().numpy()
+    assert np.abs(ret).max() < 0.5, 'a goal bonus of 1.0 was paid for a distance above the threshold'
+
+
+def test_standalone_calls_refuse_to_clobber_a_plan_in_flight():
+    from ethz_safe_learning_amd._capi import CemError
+    torch = _torch()
+    pb = hp.make_problem(seed=5)
+    _, pcfg = hp.configs(pb, N=32, H=3, P=5, E=5, k=4, I=2)
+    pl = hp.make_planner(pb, pcfg)
+    pl.plan_begin(pb['state'], seed=1, call=0)
+    pl.plan_rollout(0)
+    with pytest.raises(CemError) as e:
+        pl.fill_noise(seed=2, call=0)
+    assert e.value.status == 7
+    with pytest.raises(CemError):
+        pl.unfold_sequences(np.zeros((5, 60), np.float32), np.zeros((5, 2, 2), np.float32))
+    pl.plan_select(0); pl.plan_rollout(1); pl.plan_select(1)
+    a, s, it = pl.plan_end()
+    b, s2, _ = pl.plan(pb['state'], seed=1, call=0)            # the interrupted attempts changed nothing
+    np.testing.assert_array_equal(a, b)
+    assert s == s2 and it == 2
+    pl.fill_noise(seed=2, call=0)                               # fine once the plan has ended

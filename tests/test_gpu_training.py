@@ -92,3 +92,37 @@ def test_fit_learns_and_feeds_the_planner():
     model.fit(np.concatenate([obs, act], 1), nxt)
     assert model.model._trainer.iterations == it0 + 300
     assert model.model.learning_rate_at(300) < model.model.learning_rate_at(0)
+
+
+def test_fit_small_dataset_uses_every_epochs_own_shuffle():
+    """MlpEnsemble.fit with very few rows: an epoch is 3 steps, so the host queues many epochs' bootstrap shuffles
+    (mlp_ensemble.py:172-176) ahead of the device.  Every step must gather the rows of ITS epoch's permutation: the loss
+    trajectory equals the oracle's on the same numpy permutation sequence (a recycled permutation buffer would change it)."""
+    from ethz_safe_learning_amd.simba.models.mlp_ensemble import MlpEnsemble
+    E, D, O, L, n, steps = 2, 8, 6, 2, 40, 60
+    rng = np.random.default_rng(5)
+    X = rng.normal(0, 0.5, (n, D)).astype(np.float32)
+    Y = (0.3 * X[:, :O] + 0.05 * rng.normal(0, 1, (n, O))).astype(np.float32)
+    mdl = MlpEnsemble(D, O, E, batch_size=16, validation_split=0.0, learning_rate=0.001, learning_rate_schedule=True,
+                      training_steps=steps, mlp_params=dict(n_layers=L, units=128, activation='tf.nn.relu', dropout_rate=0.0),
+                      train_epochs=4, seed=3)
+    w64 = o.cast_weights(mdl.get_weights(), np.float64)
+    ms, vs = o.zeros_like_weights(w64), o.zeros_like_weights(w64)
+    np.random.seed(11)
+    losses = mdl.fit(X, Y)
+    # the oracle on the same permutation stream (split_train_validate draws one permutation first, mlp_ensemble.py:157-161)
+    np.random.seed(11)
+    idx = np.random.permutation(n)
+    Xt, Yt = X[idx].astype(np.float64), Y[idx].astype(np.float64)
+    bounds = np.cumsum([0] + [len(a) for a in np.array_split(np.arange(n), int(np.ceil(n / 16)))])
+    ref, step = [], 0
+    while step < steps:
+        perms = np.array([np.random.permutation(n) for _ in range(E)])
+        for b in range(len(bounds) - 1):
+            rows = perms[:, bounds[b]:bounds[b + 1]]
+            lr = o.epoch_learning_rate(step, 0.001, steps, 4)
+            ref.append(float(o.training_step(w64, ms, vs, Xt[rows], Yt[rows], lr, step + 1)))
+            step += 1
+            if step == steps:
+                break
+    np.testing.assert_allclose(losses, np.array(ref), rtol=2e-4, atol=2e-5)
