@@ -27,35 +27,46 @@ PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 SHADER_CLOCK_HZ = 2.4e9            # MI355X peak engine clock (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(pb, obs, act, K, N, H, I, k, budget_s=25.0):
-    """The oracle (a port: numpy restatement of the reference's path) timed on this box's host cores on a bounded
-    sample of the same workload: whole B2 plans until ~budget_s of CPU time is spent (at least one)."""
+def cpu_baseline(budget_s=25.0):
+    """The repo's own CPU path as SURVEY.md 8d defines it: the oracle in its fast form (oracle/cem_oracle_fast.py, a port:
+    torch-CPU fp32, one batched matmul over members per layer), timed on this box's host cores on a bounded sample of the
+    same synthetic workload: 1 warm-up + >= 3 whole plans of B2 (the headline config) and of B1 (the reference-scale config),
+    model noise drawn inside the plan as the reference does."""
+    import torch
     from oracle import cem_oracle as o      # cpu_baseline leg only
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
+    from oracle import cem_oracle_fast as of
+    from ethz_safe_learning_amd import synthetic
+    obs, act, K, I = 60, 2, 5, 5
+    pb = synthetic.problem(obs, act, K)
     sp = pb['scorer']
     osp = o.ScorerParams(goal_slice=sp.goal_slice, observe_goal_lidar=sp.observe_goal_lidar, lidar_max_dist=sp.lidar_max_dist,
                          goal_size=sp.goal_size, reward_distance=sp.reward_distance, reward_goal=sp.reward_goal,
                          reward_clip=sp.reward_clip, constrain_indicator=sp.constrain_indicator, cost_kinds=list(sp.cost_kinds))
-    cfg = o.PlanConfig(horizon=H, iterations=I, n_samples=N, n_elite=k, particles=K, ensemble_size=K, stddev_threshold=-1.0,
-                       noise_stddev=1e-3)
-    rng = np.random.default_rng(2026)
-    plans, t_total = 0, 0.0
-    while plans == 0 or (t_total < budget_s and plans < 8):
-        ea = rng.standard_normal((I, N, H, act)).astype(np.float32)
-        em = rng.standard_normal((I, H, K * N, obs)).astype(np.float32)
-        eo = rng.standard_normal((act,)).astype(np.float32)
-        t0 = time.perf_counter()
-        o.do_generate_action(pb['state'], pb['weights'], pb['inputs_min'], pb['inputs_max'], pb['low'], pb['high'],
-                             ea, em, eo, cfg, osp)
-        t_total += time.perf_counter() - t0
-        plans += 1
-    return dict(value=plans / t_total, unit='plans/s', cores=int(cores), kind='port',
-                sample='%d full B2 plan(s) (N=%d,H=%d,K=%d,I=%d) through oracle/cem_oracle.py (numpy fp32, BLAS threads=%d), '
-                       'noise generation excluded' % (plans, N, H, K, I, cores))
+    sw = of.stack_weights(pb['weights'])
+    threads = torch.get_num_threads()
+    res = {}
+    for name, N, H, share in (('B1', 500, 25, 0.3), ('B2', 2000, 30, 0.7)):
+        cfg = o.PlanConfig(horizon=H, iterations=I, n_samples=N, n_elite=N // 10, particles=K, ensemble_size=K,
+                           stddev_threshold=-1.0, noise_stddev=1e-3)
+        gen = torch.Generator().manual_seed(2026)
+        times = []
+        t_start = time.perf_counter()
+        while len(times) < 4 or (time.perf_counter() - t_start < budget_s * share and len(times) < 41):
+            ea = torch.randn((I, N, H, act), generator=gen)
+            eo = torch.randn((act,), generator=gen)
+            t0 = time.perf_counter()
+            a, s, it = of.plan(pb['state'], sw, pb['inputs_min'], pb['inputs_max'], pb['low'], pb['high'], ea, None, eo, cfg, osp)
+            times.append(time.perf_counter() - t0)
+            assert it == I and np.all(np.isfinite(a))
+        times = times[1:]                                   # the first plan is the warm-up
+        res[name] = dict(plans_per_s=1.0 / float(np.median(times)), plans_timed=len(times), median_s=float(np.median(times)),
+                         workload='obs=60 act=2 K=P=E=5 N=%d H=%d I=5 k=N/10' % (N, H))
+    return dict(value=res['B2']['plans_per_s'], unit='plans/s', cores=int(threads), kind='port', host_cpu_count=os.cpu_count(),
+                torch_num_threads=int(threads),
+                sample='median of %d whole B2 plans (N=2000,H=30,K=5,I=5) after 1 warm-up through oracle/cem_oracle_fast.py '
+                       '(torch-CPU fp32, baddbmm over members, %d intra-op threads of %s host CPUs); B1 (N=500,H=25): median of %d plans'
+                       % (res['B2']['plans_timed'], threads, os.cpu_count(), res['B1']['plans_timed']),
+                b1=res['B1'], b2=res['B2'])
 
 
 def main():
@@ -114,12 +125,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    stamps = [t0]
     for i in range(args.steps):
-        a, s, it = one_plan(args.warmup + i)
+        a, s, it = one_plan(args.warmup + i)      # synchronous: the action is back on the host when it returns
+        stamps.append(time.perf_counter())
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    step_ms = 1e3 * np.diff(np.array(stamps))
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -155,6 +169,8 @@ def main():
     out = {
         'metric': 'planning steps/sec (CEM-MPC, N=2000 K=5 H=30)', 'value': b2_equiv, 'unit': 'plans/s',
         'n_gpus': G, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+        'ms_per_step_median': float(np.median(step_ms)), 'ms_per_step_p90': float(np.percentile(step_ms, 90)),
+        'value_at_median_step': (1e3 / float(np.median(step_ms))) * (N / 2000.0),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'B2: obs=60 act=2 K=P=E=5 N=%d H=30 I=5 k=N/10 units=128 layers=4, CemMpc objective, early stop off%s'
                                % (N, '' if G == 1 else ' (weak-scaled: 2000 candidates per GPU, value in B2-equivalent plans/s)'),
@@ -168,7 +184,7 @@ def main():
                      'algorithmic_flops_per_launch': flops_launch},
     }
     if rank == 0 and G == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(pb, obs, act, K, args.n_per_gpu, H, I, args.n_per_gpu // 10)
+        out['cpu_baseline'] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

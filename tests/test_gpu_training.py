@@ -125,4 +125,8 @@ def test_fit_small_dataset_uses_every_epochs_own_shuffle():
             step += 1
             if step == steps:
                 break
-    np.testing.assert_allclose(losses, np.array(ref), rtol=2e-4, atol=2e-5)
+    # fp32 device vs fp64 oracle through 60 Adam steps at lr 1e-3: agreement decays from ~1e-6 (first epochs) to ~1e-3 relative;
+    # a step fed from another epoch's permutation changes its loss by several percent (different rows)
+    ref = np.array(ref)
+    np.testing.assert_allclose(losses[:12], ref[:12], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(losses, ref, rtol=3e-3, atol=1e-4)
