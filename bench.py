@@ -77,6 +77,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--chunks', type=int, default=0)
+    ap.add_argument('--segments', type=int, default=0, help='rollout work-queue segments: 0 auto, 1 off')
     ap.add_argument('--n-per-gpu', type=int, default=2000)
     args = ap.parse_args()
 
@@ -107,7 +108,7 @@ def main():
     pb = synthetic.problem(obs, act, K)
     cfg = PlannerConfig(obs_dim=obs, act_dim=act, ensemble_size=K, particles=K, n_samples=N, horizon=H, n_elite=k,
                         iterations=I, scorer=pb['scorer'], act_low=pb['low'], act_high=pb['high'], stddev_threshold=-1.0,
-                        noise_stddev=1e-3, variant='cem', world_size=G, rank=rank, chunks_per_tile=args.chunks,
+                        noise_stddev=1e-3, variant='cem', world_size=G, rank=rank, chunks_per_tile=args.chunks, rollout_segments=args.segments,
                         use_graph=(not distributed and not args.no_graph))
     pl = CemPlanner(cfg, device=dev)
     pl.set_weights(pb['weights'])
@@ -174,7 +175,8 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'B2: obs=60 act=2 K=P=E=5 N=%d H=30 I=5 k=N/10 units=128 layers=4, CemMpc objective, early stop off%s'
                                % (N, '' if G == 1 else ' (weak-scaled: 2000 candidates per GPU, value in B2-equivalent plans/s)'),
-                   'candidates_per_gpu': N // G, 'chunks_per_tile': pl.tiles()[0], 'workgroups': int(len(pl.tiles()[1])),
+                   'candidates_per_gpu': N // G, 'chunks_per_tile': pl.tiles()[0], 'tiles': int(len(pl.tiles()[1])),
+                   'horizon_segments': pl.segments()[0],
                    'hip_graph': bool(cfg.use_graph), 'parallelism': 'candidates sharded x%d, 1 all-gather of scores/iter' % G},
         'candidate_trajectory_steps_per_s': plans_per_s * I * N * H,
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get('CEM_MPC_LIB') or os.path.join(_HERE, 'lib', 'libcem_m
 
 EXPORTED_SYMBOLS = [
     'cem_abi_version', 'cem_status_string', 'cem_last_hip_error', 'cem_weight_blob_floats',
-    'cem_packed_weight_floats', 'cem_workspace_bytes', 'cem_pack_weights_host', 'cem_plan_tiles_host', 'cem_rollout_residency',
+    'cem_packed_weight_floats', 'cem_workspace_bytes', 'cem_pack_weights_host', 'cem_plan_tiles_host', 'cem_plan_segments_host', 'cem_rollout_residency',
     'cem_planner_create', 'cem_planner_destroy', 'cem_planner_layout', 'cem_planner_set_weights',
     'cem_planner_set_normaliser', 'cem_planner_plan', 'cem_plan_begin', 'cem_plan_rollout', 'cem_plan_select',
     'cem_plan_end', 'cem_unfold_sequences', 'cem_compute_objective', 'cem_scorer_reward', 'cem_scorer_cost', 'cem_fill_noise', 'cem_planner_set_timing', 'cem_planner_last_timing',
@@ -51,6 +51,7 @@ class CemConfig(C.Structure):
         ('act_mu0', C.c_float * CEM_MAX_ACT), ('act_sigma0', C.c_float * CEM_MAX_ACT),
         ('scorer', CemScorer),
         ('world_size', C.c_int32), ('rank', C.c_int32), ('chunks_per_tile', C.c_int32), ('use_graph', C.c_int32),
+        ('rollout_segments', C.c_int32),
     ]
 
 
@@ -96,6 +97,7 @@ def load():
         getattr(lib, f).argtypes = [cfgp]
     lib.cem_pack_weights_host.argtypes = [cfgp, vp, vp]
     lib.cem_plan_tiles_host.argtypes = [cfgp, i32p, i32p, vp, C.c_int32]
+    lib.cem_plan_segments_host.argtypes = [cfgp, i32p, i32p]
     lib.cem_rollout_residency.argtypes = [C.c_int32, C.c_int32, i32p, i32p]
     lib.cem_planner_create.argtypes = [cfgp, vp, C.c_size_t, vp, C.POINTER(vp)]
     lib.cem_planner_destroy.argtypes = [vp]

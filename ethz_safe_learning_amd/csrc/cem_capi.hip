@@ -56,6 +56,7 @@ int validate(const cem_config_t *c)
     if ((long long)c->particles * (c->n_samples / c->world_size) * c->horizon > 0x7fffffffll) return CEM_ERR_UNSUPPORTED;
     if (c->variant != CEM_VARIANT_CEM && c->variant != CEM_VARIANT_SAFE) return CEM_ERR_INVALID_ARG;
     if (c->chunks_per_tile < 0 || c->chunks_per_tile > 4) return CEM_ERR_INVALID_ARG;
+    if (c->rollout_segments < 0 || c->rollout_segments > 64) return CEM_ERR_INVALID_ARG;
     if ((long long)c->particles * c->n_samples > (1ll << 30)) return CEM_ERR_UNSUPPORTED;
     return CEM_OK;
 }
@@ -218,21 +219,46 @@ int resident_workgroups(int nfw, int rc)
     return c;
 }
 
-double tile_plan_cost(const Dims &d, int rc, size_t n_tiles)
+// ---- horizon segments -------------------------------------------------------------------------------------------------
+// One workgroup per tile for the whole horizon makes the busiest CU carry ceil(tiles / CUs) tiles while the mean is
+// tiles / CUs (B2: 3 vs 2.44).  When every tile is resident at once that ratio is lost outright; the segment work queue
+// (cem_rollout_seg_kernel) gets it back: the launch is `slots` resident workgroups drawing (tile, H / S steps) items, so a
+// CU's load is its share of tiles * S items, rounded up to one item.  Worth it only where the rounding loss is real.
+static const int kNumCUs = 256;             // MI355X; the balance arithmetic below is only used to DECIDE, any device runs either form
+static const int kSegMaxSegments = 6, kSegMinSteps = 5;
+
+int segments_for(const Dims &d, int rc, size_t n_tiles, int requested)
+{
+    if (requested == 1 || n_tiles >= (size_t)1 << 23) return 1;       // items are packed as (tile << 8 | segment)
+    auto clamp_to_horizon = [&](int S) { S = std::min(S, d.H); while (S > 1 && (d.H + S - 1) / S * (S - 1) >= d.H) --S; return std::max(S, 1); };
+    if (requested > 1) return clamp_to_horizon(requested);
+    const int occ = resident_workgroups(d.NFW, rc);
+    if (n_tiles <= (size_t)kNumCUs || n_tiles > (size_t)kNumCUs * occ) return 1;    // <= 1 tile per CU: nothing to even out; more
+                                                                                  // tiles than slots: the dispatcher already refills
+    const int S = clamp_to_horizon(std::min(kSegMaxSegments, d.H / kSegMinSteps));
+    if (S < 2) return 1;
+    const double L = (double)n_tiles / kNumCUs;
+    return std::ceil(L) / (L + 1.0 / S) > 1.05 ? S : 1;
+}
+
+double tile_plan_cost(const Dims &d, int rc, size_t n_tiles, int requested_segments)
 {
     const int occ = resident_workgroups(d.NFW, rc);
+    const int S = segments_for(d, rc, n_tiles, requested_segments);
+    if (S > 1 && n_tiles > (size_t)kNumCUs)       // work queue: mean load + one item of rounding, 2 % for the per-item prologue
+        return (double)rc * kChunkShared[d.NFW - 1][rc - 1] * ((double)n_tiles / kNumCUs + 1.0 / S) * 1.02;
     const long per_cu = (long)((n_tiles + 255) / 256);
     const long full = per_cu / occ, rem = per_cu % occ;
     auto c = [&](long resident) { return resident >= 2 ? kChunkShared[d.NFW - 1][rc - 1] : kChunkSolo[d.NFW - 1][rc - 1]; };
     return (double)rc * ((double)(full * occ) * c(occ) + (double)rem * c(rem));
 }
 
-int auto_chunks(const Dims &d)
+int auto_chunks(const Dims &d, int requested_segments)
 {
     int best = 1; double bestc = 1e30;
     for (int rc = 1; rc <= 4; ++rc) {
         std::vector<Tile6> t; build_plan_tiles(d, rc, t);
-        const double cost = tile_plan_cost(d, rc, t.size());
+        const double cost = tile_plan_cost(d, rc, t.size(), requested_segments);
         // rc ascends: a cost within 0.5 % of the best so far goes to the larger tile (fewer workgroups, less weight traffic)
         if (cost <= bestc * 1.005) { best = rc; bestc = std::min(bestc, cost); }
     }
@@ -243,8 +269,23 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
     size_t ctrl, musig, scores_local, scores_global, actions, elite, returns, costs, result, wpack, bias_h, bias_mu, bias_var,
-        nmin, ndelta, omask, kind_sel, tiles, eps_out, stamps, total;
+        nmin, ndelta, omask, kind_sel, tiles, eps_out, stamps, seg_queue, seg_flags, seg_state, total;
 };
+
+struct Plan { int rc, n_tiles, n_seg, seg_len; };
+
+// tile size, tile count and horizon segments of a configuration: one function, so workspace_bytes / create / the host helpers agree
+Plan make_plan(const cem_config_t *c, const Dims &d)
+{
+    Plan pl{};
+    pl.rc = c->chunks_per_tile ? c->chunks_per_tile : auto_chunks(d, c->rollout_segments);
+    std::vector<Tile6> t; build_plan_tiles(d, pl.rc, t);
+    pl.n_tiles = (int)t.size();
+    pl.n_seg = segments_for(d, pl.rc, t.size(), c->rollout_segments);
+    pl.seg_len = (d.H + pl.n_seg - 1) / pl.n_seg;
+    pl.n_seg = (d.H + pl.seg_len - 1) / pl.seg_len;
+    return pl;
+}
 
 Layout make_layout(const cem_config_t *c, const Dims &d, size_t max_tiles)
 {
@@ -270,8 +311,11 @@ Layout make_layout(const cem_config_t *c, const Dims &d, size_t max_tiles)
     l.tiles = take(max_tiles * sizeof(TileDesc));
     l.eps_out = take(CEM_MAX_ACT * 4);
     l.stamps = take(std::max<size_t>(max_tiles * 4 * 8, 128) * sizeof(long long));      // [tiles][4][8] rollout stamps; [64..71] select stamps
+    const Plan pl = make_plan(c, d);
+    l.seg_queue = take(256);
+    l.seg_flags = take((size_t)pl.n_tiles * std::max(pl.n_seg - 1, 1) * 4);
+    l.seg_state = take(pl.n_seg > 1 ? (size_t)pl.n_tiles * (2 * d.NFW * pl.rc * 256 + 64) * 16 : 16);
     l.total = o;
-    (void)c;
     return l;
 }
 
@@ -288,6 +332,7 @@ struct cem_planner {
     bool own_stream;
     int rc;
     int n_tiles;
+    int n_seg, seg_len;                     // horizon segments of the rollout work queue (1 = one workgroup per tile)
     bool have_weights;
     bool in_plan;
     const float *eps_act, *eps_model;       // current plan's explicit noise (device) or null
@@ -360,7 +405,7 @@ int cem_plan_tiles_host(const cem_config_t *cfg, int32_t *rc_out, int32_t *n_til
 {
     int st = validate(cfg); if (st) return st;
     const Dims d = make_dims(cfg);
-    const int rc = cfg->chunks_per_tile ? cfg->chunks_per_tile : auto_chunks(d);
+    const int rc = make_plan(cfg, d).rc;
     std::vector<Tile6> t; build_plan_tiles(d, rc, t);
     if (rc_out) *rc_out = rc;
     if (n_tiles_out) *n_tiles_out = (int32_t)t.size();
@@ -368,6 +413,16 @@ int cem_plan_tiles_host(const cem_config_t *cfg, int32_t *rc_out, int32_t *n_til
         if ((int)t.size() > max_tiles) return CEM_ERR_INVALID_ARG;
         std::memcpy(tiles_out, t.data(), t.size() * sizeof(Tile6));
     }
+    return CEM_OK;
+}
+
+int cem_plan_segments_host(const cem_config_t *cfg, int32_t *segments_out, int32_t *steps_per_segment_out)
+{
+    int st = validate(cfg); if (st) return st;
+    const Dims d = make_dims(cfg);
+    const Plan pl = make_plan(cfg, d);
+    if (segments_out) *segments_out = pl.n_seg;
+    if (steps_per_segment_out) *steps_per_segment_out = pl.seg_len;
     return CEM_OK;
 }
 
@@ -400,7 +455,7 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { g_last_hip = (int)hipGetLastError(); delete h; return CEM_ERR_HIP; }
         h->own_stream = true;
     }
-    h->rc = cfg->chunks_per_tile ? cfg->chunks_per_tile : auto_chunks(h->d);
+    { const Plan pl = make_plan(cfg, h->d); h->rc = pl.rc; h->n_seg = pl.n_seg; h->seg_len = pl.seg_len; }
     h->have_weights = false; h->in_plan = false; h->eps_act = h->eps_model = nullptr;
     h->timing = false; h->roll_ms = h->sel_ms = 0.f; h->roll_n = 0;
     h->graph = nullptr; h->gexec = nullptr; h->graph_ready = false;
@@ -549,6 +604,23 @@ hipError_t launch_rollout_t(const RolloutParams &p, int n_tiles, hipStream_t st)
     return hipGetLastError();
 }
 
+template <int RC, int NFW>
+hipError_t launch_rollout_seg_t(const RolloutParams &p, int grid, hipStream_t st)
+{
+    const size_t lds = (size_t)2 * RC * CEM_NG * 1024 + CEM_PART_FLOATS * 4;
+    hipLaunchKernelGGL((cem_rollout_seg_kernel<RC, NFW>), dim3(grid), dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_rollout_seg(int rc, int nfw, const RolloutParams &p, int grid, hipStream_t st)
+{
+#define CEM_CASE(R, F) if (rc == R && nfw == F) return launch_rollout_seg_t<R, F>(p, grid, st);
+    CEM_CASE(1, 1) CEM_CASE(2, 1) CEM_CASE(3, 1) CEM_CASE(4, 1)
+    CEM_CASE(1, 2) CEM_CASE(2, 2) CEM_CASE(3, 2) CEM_CASE(4, 2)
+#undef CEM_CASE
+    return hipErrorInvalidValue;
+}
+
 template <int MODE>
 hipError_t launch_rollout(int rc, int nfw, const RolloutParams &p, int n_tiles, hipStream_t st)
 {
@@ -599,6 +671,8 @@ int enqueue_rollout(cem_planner *h, int it)
     sp.eps_act = h->eps_act ? h->eps_act + (size_t)it * d.N * d.H * d.A : nullptr;
     sp.ctrl = (const CtrlBlock *)(ws + l.ctrl); sp.N = d.N; sp.H = d.H; sp.A = d.A; sp.it = it; sp.check_done = 1;
     for (int a = 0; a < d.A; ++a) { sp.lb[a] = h->cfg.act_lb[a]; sp.ub[a] = h->cfg.act_ub[a]; }
+    const bool queued = h->n_seg > 1 && !h->eps_model;       // explicit eps_model tensors take the general (MODE 1) kernel
+    if (queued) { sp.seg_queue = (uint32_t *)(ws + l.seg_queue); sp.seg_flags = (uint32_t *)(ws + l.seg_flags); sp.n_ready = h->n_tiles * (h->n_seg - 1); }
     const int total = d.N * d.H * ((d.A + 3) / 4);
     hipLaunchKernelGGL(cem_sample_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, h->stream, sp);
     HIPCHK(hipGetLastError());
@@ -612,7 +686,11 @@ int enqueue_rollout(cem_planner *h, int it)
     size_t e0 = 0;
     if (h->timing) { e0 = h->ev_kind.size() * 2; h->ev_kind.push_back({(int)e0, 0}); hipEventRecord(get_event(h, e0), h->stream); }
     if (rp.eps_model) HIPCHK(launch_rollout<1>(h->rc, d.NFW, rp, h->n_tiles, h->stream));
-    else HIPCHK(launch_rollout<0>(h->rc, d.NFW, rp, h->n_tiles, h->stream));
+    else if (queued) {
+        rp.seg_queue = sp.seg_queue; rp.seg_flags = sp.seg_flags; rp.seg_state = (f4 *)(ws + l.seg_state);
+        rp.seg_len = h->seg_len; rp.n_seg = h->n_seg; rp.n_tiles = h->n_tiles;
+        HIPCHK(launch_rollout_seg(h->rc, d.NFW, rp, h->n_seg * h->n_tiles, h->stream));      // one workgroup per (tile, segment) item
+    } else HIPCHK(launch_rollout<0>(h->rc, d.NFW, rp, h->n_tiles, h->stream));
     if (h->timing) hipEventRecord(get_event(h, e0 + 1), h->stream);
 
     ReduceParams qp{}; qp.ret = rp.ret; qp.costs = rp.costs; qp.scores = (float *)(ws + l.scores_local); qp.ctrl = sp.ctrl;

@@ -87,6 +87,11 @@ struct RolloutParams {
     int32_t it;
     int32_t variant, sampling, check_done;
     ScorerDev sc;
+    // horizon-segment work queue (cem_rollout_seg_kernel): items (segment, tile) in segment-major order
+    uint32_t *seg_queue;         // [2] ticket counter, FIFO tail; zeroed by the sample kernel of the same iteration
+    uint32_t *seg_flags;         // [n_tiles * (n_seg - 1)] FIFO of ready items ((tile << 8 | segment) + 1; 0 = not written yet)
+    f4 *seg_state;               // [n_tiles][2*NFW*RC*256 + 64] state a tile carries across a segment boundary
+    int32_t seg_len, n_seg, n_tiles;
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -192,6 +197,9 @@ struct WRing {
     {
         typedef unsigned int u4 __attribute__((ext_vector_type(4)));
         AGroup r;
+#ifdef CEM_DBG_NOWLOAD         // timing-only diagnostic: no weight traffic at all
+        r.a = (f4){(float)g, 1.f, 2.f, 3.f}; r.b = r.a; return r;
+#endif
         const u4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, g * 2048, 0);
         const u4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 1024, g * 2048, 0);
         r.a = __builtin_bit_cast(f4, a); r.b = __builtin_bit_cast(f4, b);
@@ -232,7 +240,9 @@ __device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], f
         if (XMODE != 0 && P >= 1) {
             // the other waves' blocks are read just in time, CEM_LDS_AHEAD groups before their MFMAs: all of them at once
             // is 24*RC live registers from group 1 on, which at RC = 3 pushes the kernel over the 256 architectural VGPRs
+#ifndef CEM_DBG_NOBARRIER      // (timing-only diagnostic builds may drop the barrier / the LDS reads; never the shipped library)
             if (P == 1 && XMODE == CEM_X_EXCHANGE) __syncthreads();   // every wave's blocks of the previous stage are in LDS
+#endif
 #pragma unroll
             for (int Q = NOWN; Q < KF; ++Q) {
                 const bool now = (P == 1) ? (Q <= 1 + CEM_LDS_AHEAD) : (Q == P + CEM_LDS_AHEAD);
@@ -240,7 +250,11 @@ __device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], f
                     const int F = L0IN ? cem_perm_l0(w, KF / 4, Q) : cem_perm_hidden(w, Q);
 #pragma unroll
                     for (int c = 0; c < RC; ++c)
+#ifdef CEM_DBG_NOLDSREAD
+                        hB[Q][c] = hB[Q & 1][c];
+#else
                         hB[Q][c] = *reinterpret_cast<const f4 *>(smem + xr + ((c * CEM_NG + F) * 64 + lane) * 16);
+#endif
                 }
             }
         }
@@ -265,17 +279,41 @@ __device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], f
 
 // MODE 0: the planner's hot path (Philox noise, no debug outputs).  MODE 1: general path — explicit eps_model
 // tensors (parity mode) and/or the trajectory / head-moment outputs of cem_unfold_sequences.
-template <int RC, int NFW, int MODE>
-__global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
+// Segment state crosses CUs — and XCDs, whose L2s are not coherent with each other for ordinary accesses.  An agent-scope
+// acquire / release FENCE would make them so by invalidating / writing back the whole L2 (buffer_inv sc1 / buffer_wbl2 sc1),
+// i.e. by evicting the ensemble weights every other workgroup of the XCD is streaming from it — measured 2.8x slower.  So the
+// few KB of state move with agent-scope RELAXED ATOMIC loads and stores (sc1 accesses: performed at the device coherence
+// point, no cache maintenance), the flag likewise, and the order "state, then flag" is kept by waiting for the stores'
+// acknowledgements (s_waitcnt vmcnt(0)) before the flag is written.
+__device__ __forceinline__ f4 cem_ld_coherent(const f4 *p)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (p.check_done && p.ctrl->done) return;
+    const float *q = reinterpret_cast<const float *>(p);
+    f4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = __hip_atomic_load(q + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+__device__ __forceinline__ void cem_st_coherent(f4 *p, const f4 v)
+{
+    float *q = reinterpret_cast<float *>(p);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) __hip_atomic_store(q + r, v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
+// One tile for steps [t_begin, t_end) of the horizon.  SEG false: the whole horizon (t_begin = 0, t_end = H).  SEG true: one
+// segment of it; what a tile carries across a segment boundary (state registers, its next layer-0 input blocks, wave 0's
+// reward / done bookkeeping) goes through p.seg_state, so any workgroup on any CU can run the tile's next segment and the
+// result is bit-identical to the unsegmented run.
+template <int RC, int NFW, int MODE, bool SEG>
+__device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *smem, const int tile_idx, const int t_begin, const int t_end)
+{
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int j = lane & 15, q = lane >> 4;
-    const TileDesc td = p.tiles[blockIdx.x];
+    const TileDesc td = p.tiles[tile_idx];
+    const bool resumed = SEG && t_begin > 0;
+    f4 *const seg_st = SEG ? p.seg_state + (size_t)tile_idx * (2 * NFW * RC * 256 + 64) : nullptr;
     const int O = p.O, A = p.A, H = p.H;
     constexpr int XB = RC * CEM_NG * 1024;
     float *part = reinterpret_cast<float *>(smem + 2 * XB);
@@ -303,6 +341,7 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
         const int f0 = 16 * (w + 4 * i) + 4 * q;
 #pragma unroll
         for (int c = 0; c < RC; ++c) {
+            if (resumed) { s[i][c] = cem_ld_coherent(seg_st + (i * RC + c) * 256 + tid); continue; }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int f = f0 + r;
@@ -351,14 +390,34 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
         d_prev = dn; c_prev = cn; } } while (0)
 
     f4 hB[CEM_NG][RC];
+    if (resumed) {
+        // the tile's state as its previous segment left it: the wave's own layer-0 input blocks go back into registers and
+        // into the LDS exchange buffer (the barrier inside the first stage publishes them), wave 0 takes the bookkeeping back
+#pragma unroll
+        for (int i = 0; i < NFW; ++i)
+#pragma unroll
+            for (int c = 0; c < RC; ++c) {
+                const f4 x = cem_ld_coherent(seg_st + ((NFW + i) * RC + c) * 256 + tid);
+                hB[i][c] = x;
+                *reinterpret_cast<f4 *>(smem + ((c * CEM_NG + w + 4 * i) * 64 + lane) * 16) = x;
+            }
+        xw = XB;
+        if (w == 0) {
+            const f4 b = cem_ld_coherent(seg_st + 2 * NFW * RC * 256 + lane);
+            d_prev = b[0]; c_prev = b[1]; cum = b[2]; done = b[3] != 0.f;
+        }
+    }
     f4 nb0 = *reinterpret_cast<const f4 *>(bias_h + 16 * (2 * w) + 4 * q);            // layer-0 bias, own blocks 2w, 2w+1
     f4 nb1 = *reinterpret_cast<const f4 *>(bias_h + 16 * (2 * w + 1) + 4 * q);
 #ifdef CEM_STAMPS
     long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev_ = (long long)__builtin_amdgcn_s_memtime();
+    st_[5] = (long long)(unsigned)__builtin_amdgcn_s_getreg(0xF804);      // HW_REG_HW_ID: which CU runs this tile
+    st_[6] = (long long)(unsigned)__builtin_amdgcn_s_getreg(0xF814);      // HW_REG_XCC_ID
+    st_[7] = tprev_;
 #endif
 
-    for (int t = -1; t < H; ++t) {
+    for (int t = resumed ? t_begin : -1; t < t_end; ++t) {
         if (t >= 0) {
             // ---- dense layers: h = relu(h W + b)  (mlp_ensemble.py:18-22).  The accumulators start at the bias
             // (x W + b with b added first: same sum, one rounding order apart); the bias of the NEXT layer is requested a
@@ -384,7 +443,7 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
                 CEM_NEXT_BIAS(p.L > 1 ? 1 : 0);
                 // stage input = previous stage's output buffer = xw ^ XB (the previous stage toggled xw after writing)
                 cem_mfma_stage<RC, 4 * NFW, NFW, true, CEM_X_EXCHANGE>(acc0, acc1, hB, wq, smem, xw ^ XB, lane, w);
-                CEM_BOOKKEEP(t - 1);                      // the barrier inside the stage published step t-1's scorer terms
+                if (!(resumed && t == t_begin)) CEM_BOOKKEEP(t - 1);   // the barrier inside the stage published step t-1's scorer terms (a resumed segment took them from seg_state)
                 CEM_RELU_PUBLISH();
                 CEM_STAMP(0);
             }
@@ -549,13 +608,76 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
     }
     // the last step's scorer terms: publish, then its bookkeeping
     __syncthreads();
-    CEM_BOOKKEEP(H - 1);
-    if (w == 0 && lane < td.cnt) p.ret[td.row_base + lane] = cum;
+    CEM_BOOKKEEP(t_end - 1);
+    if (!SEG || t_end == H) {
+        if (w == 0 && lane < td.cnt) p.ret[td.row_base + lane] = cum;
+    } else {
+#pragma unroll
+        for (int i = 0; i < NFW; ++i)
+#pragma unroll
+            for (int c = 0; c < RC; ++c) {
+                cem_st_coherent(seg_st + (i * RC + c) * 256 + tid, s[i][c]);
+                cem_st_coherent(seg_st + ((NFW + i) * RC + c) * 256 + tid, hB[i][c]);
+            }
+        if (w == 0) cem_st_coherent(seg_st + 2 * NFW * RC * 256 + lane, (f4){d_prev, c_prev, cum, done ? 1.0f : 0.0f});
+    }
 #ifdef CEM_STAMPS
-    if (p.stamps && lane == 0) for (int i = 0; i < 8; ++i) p.stamps[((size_t)blockIdx.x * 4 + w) * 8 + i] = st_[i];
+    if (p.stamps && lane == 0) for (int i = 0; i < 8; ++i) p.stamps[((size_t)tile_idx * 4 + w) * 8 + i] = st_[i];
 #endif
 }
 #undef CEM_BOOKKEEP
+
+template <int RC, int NFW, int MODE>
+__global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.check_done && p.ctrl->done) return;
+    cem_rollout_tile<RC, NFW, MODE, false>(p, smem, (int)blockIdx.x, 0, p.H);
+}
+
+// Horizon-segment work queue.  A tile is 16*RC rows for the WHOLE horizon, so a launch whose tile count is not a multiple of
+// the CU count leaves CUs idle while the busiest one finishes (B2: 625 tiles on 256 CUs = 3 on some, 2 on the others: 19 %).
+// Here the launch has one workgroup per (tile, horizon segment) ITEM.  Every workgroup draws a ticket: tickets below n_tiles
+// are the tiles' first segments; a later ticket takes the next entry of a FIFO of tiles whose previous segment has finished
+// (waiting for the entry to be written if need be).  The hardware starts the later workgroups where slots free up, i.e. on
+// the CUs that finished their items first, so a tile's segments drift to the less loaded CUs and the busiest CU no longer
+// carries a whole extra tile.  Deadlock-free for any residency: FIFO entry e is written when the e-th non-final item
+// completes; if every resident workgroup were waiting, all drawn tickets below the FIFO tail would be complete and the
+// number of completed final segments would equal n_tiles — then the tail is n_items and nobody waits.
+#define CEM_SEG_SPIN_LIMIT (1u << 23)
+template <int RC, int NFW>
+__global__ __launch_bounds__(256) void cem_rollout_seg_kernel(const RolloutParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint32_t item_s;
+    if (p.check_done && p.ctrl->done) return;
+    if (threadIdx.x == 0) {
+        const uint32_t ticket = atomicAdd(p.seg_queue, 1u);
+        uint32_t item = ticket << 8;                       // (tile << 8) | segment
+        if (ticket >= (uint32_t)p.n_tiles) {
+            const uint32_t *slot = p.seg_flags + (ticket - (uint32_t)p.n_tiles);
+            uint32_t spins = 0, v;
+            while ((v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && ++spins < CEM_SEG_SPIN_LIMIT)
+                __builtin_amdgcn_s_sleep(16);
+            item = v ? v - 1u : 0xffffffffu;               // never filled within the limit: give up rather than hang the device
+        }
+        item_s = item;
+    }
+    __syncthreads();                                       // the state loads that follow are agent-scope atomic loads themselves
+    const uint32_t item = item_s;
+    if (item == 0xffffffffu) return;
+    const int tile = (int)(item >> 8), seg = (int)(item & 255u);
+    const int t0 = seg * p.seg_len, t1 = (t0 + p.seg_len < p.H) ? t0 + p.seg_len : p.H;
+    cem_rollout_tile<RC, NFW, 0, true>(p, smem, tile, t0, t1);
+    if (t1 < p.H) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // s_waitcnt vmcnt(0): this wave's state stores are acknowledged
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t pos = atomicAdd(p.seg_queue + 1, 1u);
+            __hip_atomic_store(p.seg_flags + pos, (((uint32_t)tile << 8) | (uint32_t)(seg + 1)) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // small kernels of the optimiser loop
@@ -574,11 +696,16 @@ struct SampleParams {
     float *actions; const float *musig; const float *eps_act; const CtrlBlock *ctrl;
     int32_t N, H, A, it, check_done;
     float lb[32], ub[32];
+    uint32_t *seg_queue, *seg_flags; int32_t n_ready;      // work queue of this iteration's rollout launch, reset here (or null)
 };
 
 __global__ __launch_bounds__(256) void cem_sample_kernel(const SampleParams p)
 {
     if (p.check_done && p.ctrl->done) return;
+    if (p.seg_queue && blockIdx.x == 0) {
+        if (threadIdx.x < 2) p.seg_queue[threadIdx.x] = 0u;
+        for (int i = threadIdx.x; i < p.n_ready; i += blockDim.x) p.seg_flags[i] = 0u;
+    }
     const int AZ = (p.A + 3) >> 2;
     const int total = p.N * p.H * AZ;
     const int HA = p.H * p.A;

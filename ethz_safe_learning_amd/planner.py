@@ -59,6 +59,7 @@ class PlannerConfig:
     rank: int = 0
     chunks_per_tile: int = 0
     use_graph: bool = False
+    rollout_segments: int = 0          # 0 auto, 1 off, n > 1: horizon-segment work queue (cem_mpc.h)
 
 
 def sampling_params(low, high):
@@ -107,6 +108,7 @@ def to_c_config(cfg: PlannerConfig) -> _capi.CemConfig:
     for i, (lo, hi, size) in enumerate(s.cost_kinds):
         c.scorer.cost_lo[i], c.scorer.cost_hi[i], c.scorer.cost_size[i] = int(lo), int(hi), float(size)
     c.world_size, c.rank, c.chunks_per_tile, c.use_graph = cfg.world_size, cfg.rank, cfg.chunks_per_tile, int(cfg.use_graph)
+    c.rollout_segments = int(cfg.rollout_segments)
     return c
 
 
@@ -374,6 +376,9 @@ class CemPlanner:
         """(chunks_per_tile, tiles[n,6]) of this handle's plan (host-side logic, no GPU call)."""
         return plan_tiles(self.cfg)
 
+    def segments(self):
+        return plan_segments(self.cfg)
+
     def close(self):
         if getattr(self, 'h', None):
             self.lib.cem_planner_destroy(self.h)
@@ -394,6 +399,15 @@ def plan_tiles(cfg: PlannerConfig):
     tiles = np.zeros((nt.value, 6), np.int32)
     _capi.check(lib.cem_plan_tiles_host(C.byref(cc), C.byref(rc), C.byref(nt), _np_ptr(tiles), nt.value), 'cem_plan_tiles_host')
     return rc.value, tiles
+
+
+def plan_segments(cfg: PlannerConfig):
+    """(segments, steps per segment) of the rollout launch this configuration gets (1 segment = unsegmented)."""
+    lib = _capi.load()
+    cc = to_c_config(cfg)
+    ns, sl = C.c_int32(), C.c_int32()
+    _capi.check(lib.cem_plan_segments_host(C.byref(cc), C.byref(ns), C.byref(sl)), 'cem_plan_segments_host')
+    return ns.value, sl.value
 
 
 def pack_weights_host(cfg: PlannerConfig, weights) -> np.ndarray:

@@ -94,6 +94,9 @@ typedef struct cem_config {
     int32_t world_size, rank;
     int32_t chunks_per_tile;      /* 0 = auto; 1..4 = 16-row chunks per workgroup tile */
     int32_t use_graph;            /* 1: capture the whole plan in a hipGraph (single-rank, Philox noise only) */
+    int32_t rollout_segments;     /* 0 = auto; 1 = one workgroup per tile for the whole horizon; n > 1 = the rollout launch is a
+                                   * work queue of (tile, horizon/n) items drawn by resident workgroups — evens out CU load when the
+                                   * tile count is not a multiple of the CU count; results are bit-identical either way */
 } cem_config_t;
 
 /* Byte offsets into the caller's workspace of the arrays a host binding needs
@@ -128,6 +131,8 @@ size_t cem_workspace_bytes(const cem_config_t *cfg);
 int cem_pack_weights_host(const cem_config_t *cfg, const float *blob, float *packed);
 int cem_plan_tiles_host(const cem_config_t *cfg, int32_t *chunks_per_tile_out, int32_t *n_tiles_out,
                         int32_t *tiles_out /* [n_tiles][6]: row_base,cnt,member,act_base,noise_row_base,s0_base */, int32_t max_tiles);
+/* horizon segments the rollout launch of this configuration uses (1 = unsegmented), as cem_planner_create would choose */
+int cem_plan_segments_host(const cem_config_t *cfg, int32_t *segments_out, int32_t *steps_per_segment_out);
 
 /* diagnostic: workgroups of the rollout kernel for (chunks_per_tile, obs+act <= 64 ? 1 : 2 input blocks per wave) one CU keeps
  * resident — what the tile-size choice assumes (`table_out`) and what the HIP runtime reports (`runtime_out`, 0 without a device). */

@@ -13,6 +13,7 @@ from oracle import cem_oracle as o
 from tests.mfma_emulator import TileEmulator, dims_of
 
 from ethz_safe_learning_amd import PlannerConfig, ScorerConfig, _capi, pack_weights_host, plan_tiles
+from ethz_safe_learning_amd.planner import plan_segments
 from ethz_safe_learning_amd.planner import to_c_config
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -164,6 +165,24 @@ def test_tile_size_choice_follows_the_measured_cost_model(built_lib):
     assert rc == 2 and len(tiles) == 1280
     rc, tiles = plan_tiles(_cfg(ensemble_size=15, particles=45, n_samples=500, n_elite=20, horizon=8))   # shipped safe_cem_mpc
     assert rc == 3
+
+
+def test_horizon_segments_are_chosen_where_tiles_do_not_divide_the_cus(built_lib):
+    # B2: 625 one-chunk tiles on 256 CUs (3 on the busiest, 2.44 mean): the work queue of (tile, 5-step) items evens that out
+    assert plan_segments(_cfg()) == (6, 5)
+    assert plan_tiles(_cfg())[0] == 1
+    # B1 (157 tiles: at most one per CU), B3 / B4 (tile counts that are multiples of 256): one workgroup per tile, as before
+    assert plan_segments(_cfg(n_samples=500, horizon=25, n_elite=50))[0] == 1
+    assert plan_segments(_cfg(ensemble_size=16, particles=16, n_samples=8192, n_elite=819))[0] == 1
+    assert plan_segments(_cfg(obs_dim=100, act_dim=12, ensemble_size=8, particles=8, n_samples=4096, horizon=50, n_elite=409,
+                              act_low=[-1] * 12, act_high=[1] * 12, scorer=ScorerConfig(goal_slice=(0, 16), cost_kinds=[(16, 32, 0.2)])))[0] == 1
+    # explicit requests: off, and a count the horizon cannot fill is reduced so that no segment is empty
+    assert plan_segments(_cfg(rollout_segments=1)) == (1, 30)
+    assert plan_segments(_cfg(rollout_segments=4)) == (4, 8)
+    assert plan_segments(_cfg(horizon=7, rollout_segments=5)) == (4, 2)
+    assert plan_segments(_cfg(horizon=3, rollout_segments=8)) == (3, 1)
+    # short horizons are never segmented automatically
+    assert plan_segments(_cfg(horizon=8))[0] == 1
 
 
 def test_xcd_order_groups_members(built_lib):

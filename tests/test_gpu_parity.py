@@ -759,3 +759,50 @@ def test_standalone_calls_refuse_to_clobber_a_plan_in_flight():
     np.testing.assert_array_equal(a, b)
     assert s == s2 and it == 2
     pl.fill_noise(seed=2, call=0)                               # fine once the plan has ended
+
+
+# ------------------------------------------------------------------------------------------------- horizon-segment work queue
+@pytest.mark.parametrize('variant,O,A,E,P,N,H,rc,segs', [
+    ('cem', 60, 2, 5, 5, 96, 12, 1, 3),
+    ('safe', 60, 2, 5, 5, 96, 12, 1, 4),
+    ('safe', 60, 2, 3, 6, 40, 9, 2, 9),          # one step per segment, ragged tiles, two particles per member
+    ('cem', 100, 12, 4, 4, 70, 10, 1, 2),         # two input blocks per wave
+    ('safe', 100, 12, 2, 2, 150, 7, 3, 3),
+    ('cem', 60, 2, 5, 5, 2000, 30, 0, 0),         # B2: the shape the automatic choice segments (6 x 5 steps)
+    ('safe', 60, 2, 5, 5, 2000, 30, 0, 6),
+    ('cem', 60, 2, 5, 5, 700, 11, 4, 5),          # 64-row tiles
+])
+def test_segmented_rollout_is_bit_identical(variant, O, A, E, P, N, H, rc, segs):
+    """The rollout as a work queue of (tile, horizon segment) items, each run by whichever resident workgroup draws it
+    (cem_rollout_seg_kernel), against one workgroup per tile for the whole horizon: scores, per-row returns and the per-step
+    cost bytes bit for bit, in Philox mode (explicit eps_model tensors take the general kernel, which is never segmented)."""
+    torch = _torch()
+    pb = hp.make_problem(O, A, E, 4, seed=77)
+    out = []
+    for s_req in (1, segs):
+        _, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=max(2, N // 10), I=2, variant=variant, post=0.3, chunks_per_tile=rc,
+                             rollout_segments=s_req)
+        pl = hp.make_planner(pb, pcfg)
+        n_seg, seg_len = pl.segments()
+        if s_req == 1:
+            assert n_seg == 1
+        else:
+            assert n_seg > 1 and n_seg * seg_len >= H > (n_seg - 1) * seg_len
+        res = []
+        for rep in range(2):                                  # twice: the queue counter / flags are reset per launch
+            pl.plan_begin(pb['state'], seed=5, call=3)
+            pl.plan_rollout(0)
+            pl.plan_select(0)
+            pl.plan_rollout(1)
+            a, sc, it = pl.plan_end()
+            res.append((pl.scores_local().cpu().numpy().copy(), pl.returns().cpu().numpy().copy(),
+                        pl.costs().cpu().numpy().copy() if variant == 'safe' else None, a, sc))
+        np.testing.assert_array_equal(res[0][0], res[1][0])
+        out.append(res[0])
+        pl.close()
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    if variant == 'safe':
+        np.testing.assert_array_equal(out[0][2], out[1][2])
+    np.testing.assert_array_equal(out[0][3], out[1][3])
+    assert out[0][4] == out[1][4] and np.isfinite(out[0][0]).all()
