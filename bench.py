@@ -128,14 +128,20 @@ def main():
     cfg = PlannerConfig(obs_dim=obs, act_dim=act, ensemble_size=K, particles=K, n_samples=N, horizon=H, n_elite=k,
                         iterations=I, scorer=pb['scorer'], act_low=pb['low'], act_high=pb['high'], stddev_threshold=-1.0,
                         noise_stddev=1e-3, variant='cem', world_size=G, rank=rank, chunks_per_tile=args.chunks, rollout_segments=args.segments,
-                        use_graph=(not distributed and not args.no_graph))
+                        use_graph=(not args.no_graph))
     pl = CemPlanner(cfg, device=dev)
     pl.set_weights(pb['weights'])
     pl.set_normaliser(pb['inputs_min'], pb['inputs_max'])
+    # Multi-rank: the library owns an RCCL communicator (cem_planner_comm_init) and runs the whole sharded plan natively —
+    # kernels + one ncclAllGather of the scores per CEM iteration on the planner's stream, one hipGraph per rank.
+    # CEM_BENCH_PYTHON_EXCHANGE=1 keeps the older host-stepped form (torch.distributed all_gather between ctypes calls).
+    native = distributed and os.environ.get('CEM_BENCH_PYTHON_EXCHANGE') != '1'
+    if native:
+        pl.comm_init()
     drv = ShardedCemDriver(pl, I, world_size=G, always_exchange=distributed)
 
     def one_plan(i):
-        if not distributed:
+        if not distributed or native:
             return pl.plan(pb['state'], seed=2026, call=i)
         return drv.plan(pb['state'], seed=2026, call=i)
 
@@ -164,7 +170,7 @@ def main():
     pl.set_timing(True)
     roll_ms, roll_n = 0.0, 0
     for i in range(5):
-        if not distributed:
+        if not distributed or native:
             pl.plan(pb['state'], seed=2027, call=i)
         else:
             drv.plan(pb['state'], seed=2027, call=i)
@@ -196,7 +202,10 @@ def main():
                                % (N, '' if G == 1 else ' (weak-scaled: 2000 candidates per GPU, value in B2-equivalent plans/s)'),
                    'candidates_per_gpu': N // G, 'chunks_per_tile': pl.tiles()[0], 'tiles': int(len(pl.tiles()[1])),
                    'horizon_segments': pl.segments()[0],
-                   'hip_graph': bool(cfg.use_graph), 'parallelism': 'candidates sharded x%d, 1 all-gather of scores/iter' % G},
+                   'hip_graph': pl.graph_status() == 'graph',
+                   'exchange': 'none (1 rank)' if not distributed else ('ncclAllGather inside the library, on the planner stream' if native
+                                                                      else 'torch.distributed all_gather between ctypes calls'),
+                   'parallelism': 'candidates sharded x%d, 1 all-gather of scores/iter' % G},
         'candidate_trajectory_steps_per_s': plans_per_s * I * N * H,
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'mfma_busy_frac': mfma_util,

@@ -4,6 +4,8 @@
 #include "cem_train.h"
 #include "../../include/cem_mpc.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -323,6 +325,41 @@ size_t max_tiles_of(const Dims &d) { std::vector<Tile6> t; build_plan_tiles(d, 1
 
 }  // namespace
 
+// ---- RCCL, opened at run time: the library has no link-time dependency on it (single-GPU users never load it), and in a
+// process that already holds an RCCL (torch bundles one under the same SONAME) dlopen returns THAT copy, not a second one.
+namespace {
+struct CemNcclId { char internal[CEM_COMM_ID_BYTES]; };
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(CemNcclId *) = nullptr;
+    int (*CommInitRank)(void **, int, CemNcclId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+};
+Rccl *rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
+        if (r.lib) {
+            r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+            r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+            r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+            r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+            if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) r.lib = nullptr;
+        }
+    }
+    return r.lib ? &r : nullptr;
+}
+const int kNcclFloat32 = 7;        // ncclDataType_t ncclFloat32 (rccl.h)
+}  // namespace
+#define NCCLCHK(x) do { int e_ = (x); if (e_ != 0) { g_last_hip = e_; return CEM_ERR_COMM; } } while (0)
+
 struct cem_planner {
     cem_config_t cfg;
     Dims d;
@@ -346,6 +383,9 @@ struct cem_planner {
     hipGraph_t graph; hipGraphExec_t gexec; bool graph_ready;
     ScorerDev sc;
     float alpha, beta;
+    void *comm;                              // ncclComm_t of cem_planner_comm_init, or null (the host exchanges scores_local -> scores_global)
+    int plans_since_comm;                    // the first plan after comm_init runs eagerly (RCCL sets itself up lazily), then the graph is captured
+    bool graph_failed;                       // capture with the collective did not work on this stack: stay eager
     size_t sel_dyn_limit;                    // dynamic-LDS allowance of the select kernels on this handle's device
     // grow-only device scratch of the standalone ops (unfold_sequences tiles + returns, compute_objective returns + costs)
     char *scratch; size_t scratch_bytes;
@@ -366,7 +406,8 @@ const char *cem_status_string(int s)
     case CEM_ERR_WORKSPACE: return "workspace too small or misaligned";
     case CEM_ERR_HIP: return "HIP runtime error (see cem_last_hip_error)";
     case CEM_ERR_NO_WEIGHTS: return "set_weights has not been called";
-    case CEM_ERR_STATE: return "stepwise plan calls out of order";
+    case CEM_ERR_STATE: return "stepwise plan calls out of order, or a standalone call while a plan is in flight";
+    case CEM_ERR_COMM: return "RCCL: library not found or a collective call failed (see cem_last_hip_error for the ncclResult_t)";
     default: return "unknown status";
     }
 }
@@ -459,6 +500,7 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
     h->have_weights = false; h->in_plan = false; h->eps_act = h->eps_model = nullptr;
     h->timing = false; h->roll_ms = h->sel_ms = 0.f; h->roll_n = 0;
     h->graph = nullptr; h->gexec = nullptr; h->graph_ready = false;
+    h->comm = nullptr; h->plans_since_comm = 0; h->graph_failed = false;
     h->h_ctrl = nullptr; h->h_result = nullptr;
     h->scratch = nullptr; h->scratch_bytes = 0;
     // every failure from here on frees what was acquired and reports the HIP code
@@ -528,6 +570,7 @@ int cem_planner_destroy(cem_planner_t *h)
 {
     if (!h) return CEM_ERR_INVALID_ARG;
     if (h->scratch) hipFree(h->scratch);
+    if (h->comm) { if (Rccl *r = rccl()) r->CommDestroy(h->comm); h->comm = nullptr; }
     if (h->gexec) hipGraphExecDestroy(h->gexec);
     if (h->graph) hipGraphDestroy(h->graph);
     for (auto e : h->ev) hipEventDestroy(e);
@@ -723,6 +766,17 @@ int enqueue_select(cem_planner *h, int it)
     return CEM_OK;
 }
 
+// the one exchange step of an iteration: every rank's N/world local scores -> all N scores on every rank
+int enqueue_exchange(cem_planner *h)
+{
+    if (!h->comm) return CEM_OK;
+    Rccl *r = rccl(); if (!r) return CEM_ERR_COMM;
+    const Dims &d = h->d; const Layout &l = h->lay;
+    // world 1: scores_global aliases scores_local and the all-gather is the in-place form (sendbuff == recvbuff + rank * count)
+    NCCLCHK(r->AllGather(h->ws + l.scores_local, h->ws + l.scores_global, (size_t)d.Nloc, kNcclFloat32, h->comm, h->stream));
+    return CEM_OK;
+}
+
 int enqueue_end(cem_planner *h, bool have_eps_out)
 {
     const Dims &d = h->d; const Layout &l = h->lay; char *ws = h->ws;
@@ -812,33 +866,107 @@ int cem_planner_plan(cem_planner_t *h, const float *state, uint64_t seed, uint64
 {
     if (!h || !state) return CEM_ERR_INVALID_ARG;
     if (!h->have_weights) return CEM_ERR_NO_WEIGHTS;
-    if (h->d.W != 1) return CEM_ERR_STATE;         // sharded ranks must use the stepwise calls around their collective
-    const bool graphable = h->cfg.use_graph && !eps_act_dev && !eps_model_dev && !eps_out_host && !h->timing;
+    if (h->d.W != 1 && !h->comm) return CEM_ERR_STATE;   // sharded ranks without cem_planner_comm_init use the stepwise calls around their own collective
+    // With a communicator the first plan runs eagerly: RCCL finishes its lazy set-up (buffers, kernels) outside any capture.
+    const bool graphable = h->cfg.use_graph && !eps_act_dev && !eps_model_dev && !eps_out_host && !h->timing && !h->graph_failed &&
+                           (!h->comm || h->plans_since_comm > 0);
+    if (h->comm) h->plans_since_comm++;
     if (graphable) {
         stage_ctrl(h, state, seed, call);
         if (!h->graph_ready) {
             h->eps_act = h->eps_model = nullptr;
-            HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            // relaxed mode: RCCL may touch the runtime from its proxy thread while this thread captures
+            HIPCHK(hipStreamBeginCapture(h->stream, h->comm ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
             int st = enqueue_begin(h);
-            for (int it = 0; it < h->d.I && !st; ++it) { st = enqueue_rollout(h, it); if (!st) st = enqueue_select(h, it); }
+            for (int it = 0; it < h->d.I && !st; ++it) {
+                st = enqueue_rollout(h, it);
+                if (!st) st = enqueue_exchange(h);
+                if (!st) st = enqueue_select(h, it);
+            }
             if (!st) st = enqueue_end(h, false);
             hipError_t ce = hipStreamEndCapture(h->stream, &h->graph);
-            if (st) return st;
-            HIPCHK(ce);
-            HIPCHK(hipGraphInstantiate(&h->gexec, h->graph, nullptr, nullptr, 0));
-            h->graph_ready = true;
+            if (!st && ce == hipSuccess) ce = hipGraphInstantiate(&h->gexec, h->graph, nullptr, nullptr, 0);
+            if (st || ce != hipSuccess) {
+                if (!h->comm) { if (st) return st; HIPCHK(ce); }
+                // a captured collective is not something every RCCL / runtime pair supports: fall back to eager launches for good
+                (void)hipGetLastError();
+                if (h->graph) { hipGraphDestroy(h->graph); h->graph = nullptr; }
+                h->gexec = nullptr; h->graph_failed = true;
+            } else {
+                h->graph_ready = true;
+            }
         }
-        HIPCHK(hipGraphLaunch(h->gexec, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        read_result(h, action_out, best_score_out, iters_out);
-        return CEM_OK;
+        if (h->graph_ready) {
+            HIPCHK(hipGraphLaunch(h->gexec, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            read_result(h, action_out, best_score_out, iters_out);
+            return CEM_OK;
+        }
     }
     int st = cem_plan_begin(h, state, seed, call, eps_act_dev, eps_model_dev); if (st) return st;
     for (int it = 0; it < h->d.I; ++it) {
         st = cem_plan_rollout(h, it); if (st) return st;
+        st = enqueue_exchange(h); if (st) return st;
         st = cem_plan_select(h, it); if (st) return st;
     }
     return cem_plan_end(h, eps_out_host, action_out, best_score_out, iters_out);
+}
+
+int cem_comm_unique_id(void *id_out)
+{
+    if (!id_out) return CEM_ERR_INVALID_ARG;
+    Rccl *r = rccl(); if (!r) return CEM_ERR_COMM;
+    CemNcclId id;
+    NCCLCHK(r->GetUniqueId(&id));
+    std::memcpy(id_out, id.internal, CEM_COMM_ID_BYTES);
+    return CEM_OK;
+}
+
+int cem_planner_comm_init(cem_planner_t *h, const void *id, int32_t n_ranks, int32_t rank)
+{
+    if (!h || !id) return CEM_ERR_INVALID_ARG;
+    if (n_ranks != h->d.W || rank != h->d.R) return CEM_ERR_INVALID_ARG;       // the communicator IS the candidate sharding of this handle
+    if (h->in_plan) return CEM_ERR_STATE;
+    Rccl *r = rccl(); if (!r) return CEM_ERR_COMM;
+    if (h->comm) { r->CommDestroy(h->comm); h->comm = nullptr; }
+    CemNcclId nid; std::memcpy(nid.internal, id, CEM_COMM_ID_BYTES);
+    void *comm = nullptr;
+    NCCLCHK(r->CommInitRank(&comm, n_ranks, nid, rank));
+    h->comm = comm; h->plans_since_comm = 0;
+    // a graph captured without the collective (world 1) no longer describes the plan
+    if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+    if (h->graph) { hipGraphDestroy(h->graph); h->graph = nullptr; }
+    h->graph_ready = false; h->graph_failed = false;
+    return CEM_OK;
+}
+
+int cem_planner_comm_destroy(cem_planner_t *h)
+{
+    if (!h) return CEM_ERR_INVALID_ARG;
+    if (h->in_plan) return CEM_ERR_STATE;
+    if (h->comm) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (Rccl *r = rccl()) r->CommDestroy(h->comm);
+        h->comm = nullptr;
+        if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+        if (h->graph) { hipGraphDestroy(h->graph); h->graph = nullptr; }
+        h->graph_ready = false;
+    }
+    return CEM_OK;
+}
+
+int cem_planner_graph_status(const cem_planner_t *h, int32_t *status_out)
+{
+    if (!h || !status_out) return CEM_ERR_INVALID_ARG;
+    *status_out = h->graph_ready ? 1 : (h->graph_failed ? 2 : 0);
+    return CEM_OK;
+}
+
+int cem_plan_exchange(cem_planner_t *h)
+{
+    if (!h) return CEM_ERR_INVALID_ARG;
+    if (!h->in_plan || !h->comm) return CEM_ERR_STATE;
+    return enqueue_exchange(h);
 }
 
 // grow-only device scratch of the standalone ops, cached on the handle (a hipMalloc / hipFree pair per call is a

@@ -163,6 +163,7 @@ class CemPlanner:
         _capi.check(self.lib.cem_planner_layout(self.h, C.byref(lay)), 'cem_planner_layout')
         self.layout = lay
         self._call = 0
+        self.has_comm = False
 
     # ------------------------------------------------------------------ stream plumbing
     def _wait_inputs(self):
@@ -227,6 +228,46 @@ class CemPlanner:
         if mn.shape != (self.cfg.obs_dim + self.cfg.act_dim,) or mx.shape != mn.shape:
             raise ValueError('normaliser must have shape [obs_dim + act_dim]')
         _capi.check(self.lib.cem_planner_set_normaliser(self.h, _np_ptr(mn), _np_ptr(mx)), 'cem_planner_set_normaliser')
+
+    # ------------------------------------------------------------------ native exchange (RCCL inside the library)
+    def comm_init(self, group=None):
+        """Give the handle its own RCCL communicator over the ranks of ``group`` (default: the world), so that ``plan()`` runs
+        the whole candidate-sharded plan — kernels and the per-iteration all-gather of the scores — inside the library, as one
+        hipGraph per rank when ``use_graph`` is set.  Collective: every rank of the group calls it.  torch.distributed only
+        carries the 128-byte communicator id from rank 0 to the others; with world_size 1 it is not needed at all."""
+        c = self.cfg
+        buf = (C.c_char * _capi.CEM_COMM_ID_BYTES)()
+        if c.world_size > 1:
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError('comm_init for world_size > 1 needs an initialised torch.distributed process group (it carries the id)')
+            if dist.get_world_size(group) != c.world_size or dist.get_rank(group) != c.rank:
+                raise ValueError('the process group does not match the planner\'s (world_size, rank)')
+            box = [None]
+            if c.rank == 0:
+                _capi.check(self.lib.cem_comm_unique_id(buf), 'cem_comm_unique_id')
+                box[0] = bytes(buf.raw)
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=group)
+            buf.raw = box[0]
+        else:
+            _capi.check(self.lib.cem_comm_unique_id(buf), 'cem_comm_unique_id')
+        with self._torch.cuda.device(self.device):
+            _capi.check(self.lib.cem_planner_comm_init(self.h, buf, c.world_size, c.rank), 'cem_planner_comm_init')
+        self.has_comm = True
+
+    def comm_destroy(self):
+        _capi.check(self.lib.cem_planner_comm_destroy(self.h), 'cem_planner_comm_destroy')
+        self.has_comm = False
+
+    def graph_status(self):
+        """'eager' | 'graph' | 'graph-unsupported' (cem_planner_graph_status)."""
+        st = C.c_int32()
+        _capi.check(self.lib.cem_planner_graph_status(self.h, C.byref(st)), 'cem_planner_graph_status')
+        return ('eager', 'graph', 'graph-unsupported')[st.value]
+
+    def plan_exchange(self):
+        _capi.check(self.lib.cem_plan_exchange(self.h), 'cem_plan_exchange')
 
     # ------------------------------------------------------------------ planning
     def _noise_args(self, eps_act, eps_model):

@@ -13,6 +13,12 @@ replicated sigma, so ranks agree without further traffic (cem_mpc.py:66-67).
 ``backend`` is anything with plan_begin / plan_rollout / plan_select / plan_end
 and scores_local() / scores_global() tensors; in production it is a
 ``CemPlanner`` (HIP).  The driver itself never computes.
+
+This host-stepped driver is the portable form (any torch.distributed backend:
+the gloo test ranks on CPU use it).  On GPUs the preferred form is
+``CemPlanner.comm_init()`` + ``CemPlanner.plan()``: the library then owns an RCCL
+communicator and runs the same loop — all-gather included — natively, as one
+hipGraph per rank.
 """
 from __future__ import annotations
 
@@ -26,6 +32,9 @@ class ShardedCemDriver:
         self.always_exchange = always_exchange      # issue the collective even for one rank (exercises RCCL on a one-GPU box)
 
     def exchange(self):
+        if getattr(self.backend, 'has_comm', False):
+            self.backend.plan_exchange()              # the handle's own RCCL communicator (cem_plan_exchange): no torch in the loop
+            return
         if self.world_size == 1 and not self.always_exchange:
             return
         import contextlib

@@ -41,7 +41,8 @@ enum cem_status {
     CEM_ERR_WORKSPACE = 4,       /* workspace too small / misaligned */
     CEM_ERR_HIP = 5,             /* a HIP runtime call failed; cem_last_hip_error() has the code */
     CEM_ERR_NO_WEIGHTS = 6,      /* plan() before set_weights() */
-    CEM_ERR_STATE = 7            /* stepwise calls out of order, or a call that would clobber the state of a plan in flight */
+    CEM_ERR_STATE = 7,           /* stepwise calls out of order, or a call that would clobber the state of a plan in flight */
+    CEM_ERR_COMM = 8             /* librccl could not be opened, or an RCCL call failed (cem_last_hip_error() holds the ncclResult_t) */
 };
 
 enum cem_variant { CEM_VARIANT_CEM = 0 /* CemMpc */, CEM_VARIANT_SAFE = 1 /* SafeCemMpc */ };
@@ -163,6 +164,22 @@ int cem_plan_begin(cem_planner_t *h, const float *state, uint64_t seed, uint64_t
 int cem_plan_rollout(cem_planner_t *h, int32_t it);   /* sample actions, roll out + score this rank's candidates -> scores_local */
 int cem_plan_select(cem_planner_t *h, int32_t it);    /* top-k / moments refit / best-so-far / early-stop on scores_global */
 int cem_plan_end(cem_planner_t *h, const float *eps_out_host, float *action_out, float *best_score_out, int32_t *iters_out);
+
+/* The exchange step inside the library: an RCCL communicator owned by the handle, so that a candidate-sharded
+ * plan runs without the host between its kernels — cem_planner_plan() then works for world_size > 1 (rollout ->
+ * ncclAllGather of the N/world local scores on the handle's stream -> select, per iteration) and, with use_graph, replays
+ * it as ONE hipGraph per rank including the collectives.  librccl is opened at run time (dlopen), not linked.
+ * Rank 0 calls cem_comm_unique_id() and hands the 128 bytes to the other ranks by any means (torch.distributed broadcast,
+ * MPI, a file); every rank then calls cem_planner_comm_init() — collectively, like ncclCommInitRank.
+ * cem_plan_exchange() is the same all-gather for the stepwise API (between cem_plan_rollout and cem_plan_select). */
+#define CEM_COMM_ID_BYTES 128
+int cem_comm_unique_id(void *id_out /* CEM_COMM_ID_BYTES */);
+int cem_planner_comm_init(cem_planner_t *h, const void *id /* CEM_COMM_ID_BYTES */, int32_t n_ranks, int32_t rank);
+int cem_planner_comm_destroy(cem_planner_t *h);
+int cem_plan_exchange(cem_planner_t *h);
+/* 0: cem_planner_plan launches kernel by kernel; 1: it replays a captured hipGraph; 2: capturing was tried and is not supported
+ * with this communicator / runtime (the plan then stays kernel by kernel — same results) */
+int cem_planner_graph_status(const cem_planner_t *h, int32_t *status_out);
 
 /* TransitionModel.unfold_sequences (transition_model.py:64-77) as an API of its own:
  * s0[B][obs], actions[B][H][A] (device) -> traj[B][H+1][obs] (device); optional mu/stddev[B][H][obs].

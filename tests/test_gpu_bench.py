@@ -50,4 +50,17 @@ def test_distributed_leg_with_one_rank_over_rccl():
     assert out.returncode == 0, out.stderr[-2000:]
     r = _json_line(out.stdout)
     _check(r, 5, 2)
-    assert r['config']['hip_graph'] is False                  # the multi-rank leg launches stepwise around the collective
+    # the multi-rank leg is the library's own: RCCL all-gather inside the captured per-rank graph
+    assert r['config']['hip_graph'] is True and 'ncclAllGather' in r['config']['exchange']
+
+
+def test_distributed_leg_host_stepped_fallback():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, CEM_BENCH_FORCE_DIST='1', CEM_BENCH_PYTHON_EXCHANGE='1')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+                          '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '5',
+                          '--warmup', '2', '--no-cpu-baseline'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = _json_line(out.stdout)
+    _check(r, 5, 2)
+    assert r['config']['hip_graph'] is False and 'torch.distributed' in r['config']['exchange']

@@ -89,3 +89,37 @@ def test_rccl_exchange_on_the_planner_stream_single_rank():
     for (a, sc, it), (ra, rs, rit) in zip(res, ref):
         np.testing.assert_array_equal(a, ra)
         assert sc == rs and it == rit
+
+
+def test_native_rccl_exchange_inside_the_library():
+    """cem_planner_comm_init: the handle owns an RCCL communicator and cem_planner_plan runs rollout -> ncclAllGather -> select
+    natively, eagerly on the first call and as one captured hipGraph afterwards.  One GPU allows one RCCL rank, so world_size
+    is 1 here (the all-gather is then RCCL's in-place copy); every plan must equal the plan of a handle without a communicator,
+    and the stepwise API with cem_plan_exchange likewise."""
+    import torch
+    from tests import helpers as hp
+    pb = hp.make_problem(seed=83)
+    N, H, P, E, k, I = 512, 10, 5, 5, 51, 3
+    _, ref_cfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, variant='safe', post=0.3, noise=0.02, use_graph=True)
+    ref = hp.make_planner(pb, ref_cfg)
+    expect = [ref.plan(pb['state'], seed=23, call=c) for c in range(4)]
+    _, cfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, variant='safe', post=0.3, noise=0.02, use_graph=True)
+    pl = hp.make_planner(pb, cfg)
+    pl.comm_init()
+    for c in range(4):                                   # call 0 eager (RCCL warms up), call 1 captures, 2-3 replay
+        a, s, it = pl.plan(pb['state'], seed=23, call=c)
+        np.testing.assert_array_equal(a, expect[c][0])
+        assert s == expect[c][1] and it == expect[c][2]
+        assert pl.graph_status() == ('eager' if c == 0 else 'graph'), 'the plan with its collective should replay as one hipGraph'
+    # stepwise, with the exchange issued by the library
+    pl.plan_begin(pb['state'], seed=23, call=1)
+    for it in range(I):
+        pl.plan_rollout(it)
+        pl.plan_exchange()
+        pl.plan_select(it)
+    a, s, it = pl.plan_end()
+    np.testing.assert_array_equal(a, expect[1][0])
+    assert s == expect[1][1]
+    pl.comm_destroy()
+    a, s, it = pl.plan(pb['state'], seed=23, call=2)     # and back to the communicator-less graph
+    np.testing.assert_array_equal(a, expect[2][0])
