@@ -210,7 +210,7 @@ def main():
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'mfma_busy_frac': mfma_util,
                      'hbm_gbps': (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None, 'hbm_peak_gbps': PEAK_HBM_GBPS,
-                     'kernel': 'cem_rollout_kernel', 'avg_launch_ms': avg_ms, 'launches_timed': roll_n,
+                     'kernel': 'cem_rollout_seg_kernel<1, 1>' if pl.segments()[0] > 1 else 'cem_rollout_kernel<%d, 1, 0>' % pl.tiles()[0], 'avg_launch_ms': avg_ms, 'launches_timed': roll_n,
                      'algorithmic_flops_per_launch': flops_launch},
     }
     if rank == 0 and G == 1 and not args.no_cpu_baseline:

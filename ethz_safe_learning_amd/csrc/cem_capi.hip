@@ -221,13 +221,18 @@ int resident_workgroups(int nfw, int rc)
     return c;
 }
 
-// ---- horizon segments -------------------------------------------------------------------------------------------------
+// ---- pinned tiles + floating horizon segments ----------------------------------------------------------------------------
 // One workgroup per tile for the whole horizon makes the busiest CU carry ceil(tiles / CUs) tiles while the mean is
-// tiles / CUs (B2: 3 vs 2.44).  When every tile is resident at once that ratio is lost outright; the segment work queue
-// (cem_rollout_seg_kernel) gets it back: the launch is `slots` resident workgroups drawing (tile, H / S steps) items, so a
-// CU's load is its share of tiles * S items, rounded up to one item.  Worth it only where the rounding loss is real.
+// tiles / CUs (B2: 3 vs 2.44).  When every tile is resident at once that ratio is lost outright.  cem_rollout_seg_kernel gets
+// most of it back: floor(tiles / CUs) tiles per CU stay whole ("pinned"), the remainder "float" — cut into S horizon segments
+// that run, at raised priority, in whatever slot is free, so every CU carries about the same share of them.
+// Measured on MI355X (scripts/sweep_seg.py, profiles/r02_sweep_floating_segments.jsonl): B2 0.475 -> 0.405 ms with S = 4..15;
+// no gain with ONE pinned tile per CU (375 / 470 tiles: 0.335 -> 0.335, 0.353 -> 0.373 ms: the pinned tile runs without a
+// partner and a floater's 30-step chain plus its hand-overs is as long as two whole tiles) and none when the remainder nearly
+// fills the CUs anyway (750 tiles: 0.498 -> 0.492).  Hence: at least two pinned tiles per CU, and a predicted gain of > 4 %.
 static const int kNumCUs = 256;             // MI355X; the balance arithmetic below is only used to DECIDE, any device runs either form
 static const int kSegMaxSegments = 6, kSegMinSteps = 5;
+static const double kFloatOverhead = 1.08;  // floating launch vs the mean-load ideal (B2: 0.405 ms vs 2.44 x 0.153 ms)
 
 int segments_for(const Dims &d, int rc, size_t n_tiles, int requested)
 {
@@ -235,20 +240,22 @@ int segments_for(const Dims &d, int rc, size_t n_tiles, int requested)
     auto clamp_to_horizon = [&](int S) { S = std::min(S, d.H); while (S > 1 && (d.H + S - 1) / S * (S - 1) >= d.H) --S; return std::max(S, 1); };
     if (requested > 1) return clamp_to_horizon(requested);
     const int occ = resident_workgroups(d.NFW, rc);
-    if (n_tiles <= (size_t)kNumCUs || n_tiles > (size_t)kNumCUs * occ) return 1;    // <= 1 tile per CU: nothing to even out; more
-                                                                                  // tiles than slots: the dispatcher already refills
+    if (n_tiles < (size_t)2 * kNumCUs || n_tiles > (size_t)kNumCUs * occ) return 1;  // < 2 pinned tiles per CU: no gain (measured);
+                                                                                  // more tiles than slots: the dispatcher already refills
     const int S = clamp_to_horizon(std::min(kSegMaxSegments, d.H / kSegMinSteps));
     if (S < 2) return 1;
     const double L = (double)n_tiles / kNumCUs;
-    return std::ceil(L) / (L + 1.0 / S) > 1.05 ? S : 1;
+    return std::ceil(L) / (kFloatOverhead * L) > 1.04 ? S : 1;
 }
 
 double tile_plan_cost(const Dims &d, int rc, size_t n_tiles, int requested_segments)
 {
     const int occ = resident_workgroups(d.NFW, rc);
     const int S = segments_for(d, rc, n_tiles, requested_segments);
-    if (S > 1 && n_tiles > (size_t)kNumCUs)       // work queue: mean load + one item of rounding, 2 % for the per-item prologue
-        return (double)rc * kChunkShared[d.NFW - 1][rc - 1] * ((double)n_tiles / kNumCUs + 1.0 / S) * 1.02;
+    if (S > 1 && n_tiles > (size_t)kNumCUs) {     // pinned tiles + floating segments: every CU carries the mean load, plus hand-over costs
+        const bool alone = n_tiles / kNumCUs < 2;  // one pinned tile per CU: it runs without a partner most of the time
+        return (double)rc * (alone ? kChunkSolo : kChunkShared)[d.NFW - 1][rc - 1] * ((double)n_tiles / kNumCUs) * kFloatOverhead;
+    }
     const long per_cu = (long)((n_tiles + 255) / 256);
     const long full = per_cu / occ, rem = per_cu % occ;
     auto c = [&](long resident) { return resident >= 2 ? kChunkShared[d.NFW - 1][rc - 1] : kChunkSolo[d.NFW - 1][rc - 1]; };
@@ -274,7 +281,7 @@ struct Layout {
         nmin, ndelta, omask, kind_sel, tiles, eps_out, stamps, seg_queue, seg_flags, seg_state, total;
 };
 
-struct Plan { int rc, n_tiles, n_seg, seg_len; };
+struct Plan { int rc, n_tiles, n_seg, seg_len, n_pinned; };
 
 // tile size, tile count and horizon segments of a configuration: one function, so workspace_bytes / create / the host helpers agree
 Plan make_plan(const cem_config_t *c, const Dims &d)
@@ -286,6 +293,9 @@ Plan make_plan(const cem_config_t *c, const Dims &d)
     pl.n_seg = segments_for(d, pl.rc, t.size(), c->rollout_segments);
     pl.seg_len = (d.H + pl.n_seg - 1) / pl.n_seg;
     pl.n_seg = (d.H + pl.seg_len - 1) / pl.seg_len;
+    // tiles every CU gets the same number of stay whole ("pinned"); only the remainder floats in segments
+    pl.n_pinned = pl.n_seg > 1 ? (pl.n_tiles / kNumCUs) * kNumCUs : pl.n_tiles;
+    if (c->rollout_segments > 1 && pl.n_pinned == pl.n_tiles && pl.n_seg > 1) pl.n_pinned = 0;   // an explicit request floats everything
     return pl;
 }
 
@@ -315,8 +325,9 @@ Layout make_layout(const cem_config_t *c, const Dims &d, size_t max_tiles)
     l.stamps = take(std::max<size_t>(max_tiles * 4 * 8, 128) * sizeof(long long));      // [tiles][4][8] rollout stamps; [64..71] select stamps
     const Plan pl = make_plan(c, d);
     l.seg_queue = take(256);
-    l.seg_flags = take((size_t)pl.n_tiles * std::max(pl.n_seg - 1, 1) * 4);
-    l.seg_state = take(pl.n_seg > 1 ? (size_t)pl.n_tiles * (2 * d.NFW * pl.rc * 256 + 64) * 16 : 16);
+    const size_t n_float = (size_t)(pl.n_tiles - pl.n_pinned);
+    l.seg_flags = take(std::max<size_t>(n_float * std::max(pl.n_seg - 1, 1), 1) * 4);
+    l.seg_state = take(pl.n_seg > 1 ? std::max<size_t>(n_float, 1) * (2 * d.NFW * pl.rc * 256 + 64) * 16 : 16);
     l.total = o;
     return l;
 }
@@ -369,7 +380,7 @@ struct cem_planner {
     bool own_stream;
     int rc;
     int n_tiles;
-    int n_seg, seg_len;                     // horizon segments of the rollout work queue (1 = one workgroup per tile)
+    int n_seg, seg_len, n_pinned;           // horizon segments of the floating tiles (1 = one workgroup per tile), tiles that stay whole
     bool have_weights;
     bool in_plan;
     const float *eps_act, *eps_model;       // current plan's explicit noise (device) or null
@@ -496,7 +507,7 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { g_last_hip = (int)hipGetLastError(); delete h; return CEM_ERR_HIP; }
         h->own_stream = true;
     }
-    { const Plan pl = make_plan(cfg, h->d); h->rc = pl.rc; h->n_seg = pl.n_seg; h->seg_len = pl.seg_len; }
+    { const Plan pl = make_plan(cfg, h->d); h->rc = pl.rc; h->n_seg = pl.n_seg; h->seg_len = pl.seg_len; h->n_pinned = pl.n_pinned; }
     h->have_weights = false; h->in_plan = false; h->eps_act = h->eps_model = nullptr;
     h->timing = false; h->roll_ms = h->sel_ms = 0.f; h->roll_n = 0;
     h->graph = nullptr; h->gexec = nullptr; h->graph_ready = false;
@@ -715,7 +726,7 @@ int enqueue_rollout(cem_planner *h, int it)
     sp.ctrl = (const CtrlBlock *)(ws + l.ctrl); sp.N = d.N; sp.H = d.H; sp.A = d.A; sp.it = it; sp.check_done = 1;
     for (int a = 0; a < d.A; ++a) { sp.lb[a] = h->cfg.act_lb[a]; sp.ub[a] = h->cfg.act_ub[a]; }
     const bool queued = h->n_seg > 1 && !h->eps_model;       // explicit eps_model tensors take the general (MODE 1) kernel
-    if (queued) { sp.seg_queue = (uint32_t *)(ws + l.seg_queue); sp.seg_flags = (uint32_t *)(ws + l.seg_flags); sp.n_ready = h->n_tiles * (h->n_seg - 1); }
+    if (queued) { sp.seg_queue = (uint32_t *)(ws + l.seg_queue); sp.seg_flags = (uint32_t *)(ws + l.seg_flags); sp.n_ready = (h->n_tiles - h->n_pinned) * (h->n_seg - 1); }
     const int total = d.N * d.H * ((d.A + 3) / 4);
     hipLaunchKernelGGL(cem_sample_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, h->stream, sp);
     HIPCHK(hipGetLastError());
@@ -731,8 +742,9 @@ int enqueue_rollout(cem_planner *h, int it)
     if (rp.eps_model) HIPCHK(launch_rollout<1>(h->rc, d.NFW, rp, h->n_tiles, h->stream));
     else if (queued) {
         rp.seg_queue = sp.seg_queue; rp.seg_flags = sp.seg_flags; rp.seg_state = (f4 *)(ws + l.seg_state);
-        rp.seg_len = h->seg_len; rp.n_seg = h->n_seg; rp.n_tiles = h->n_tiles;
-        HIPCHK(launch_rollout_seg(h->rc, d.NFW, rp, h->n_seg * h->n_tiles, h->stream));      // one workgroup per (tile, segment) item
+        rp.seg_len = h->seg_len; rp.n_seg = h->n_seg; rp.n_tiles = h->n_tiles; rp.n_pinned = h->n_pinned;
+        // one workgroup per pinned tile, then one per (floating tile, segment) item
+        HIPCHK(launch_rollout_seg(h->rc, d.NFW, rp, h->n_pinned + h->n_seg * (h->n_tiles - h->n_pinned), h->stream));
     } else HIPCHK(launch_rollout<0>(h->rc, d.NFW, rp, h->n_tiles, h->stream));
     if (h->timing) hipEventRecord(get_event(h, e0 + 1), h->stream);
 

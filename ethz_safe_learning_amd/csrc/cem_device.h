@@ -89,9 +89,9 @@ struct RolloutParams {
     ScorerDev sc;
     // horizon-segment work queue (cem_rollout_seg_kernel): items (segment, tile) in segment-major order
     uint32_t *seg_queue;         // [2] ticket counter, FIFO tail; zeroed by the sample kernel of the same iteration
-    uint32_t *seg_flags;         // [n_tiles * (n_seg - 1)] FIFO of ready items ((tile << 8 | segment) + 1; 0 = not written yet)
-    f4 *seg_state;               // [n_tiles][2*NFW*RC*256 + 64] state a tile carries across a segment boundary
-    int32_t seg_len, n_seg, n_tiles;
+    uint32_t *seg_flags;         // [n_float * (n_seg - 1)] FIFO of ready floating items ((tile << 8 | segment) + 1; 0 = not written yet)
+    f4 *seg_state;               // [n_float][2*NFW*RC*256 + 64] state a floating tile carries across a segment boundary
+    int32_t seg_len, n_seg, n_tiles, n_pinned;
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -313,7 +313,7 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
     const int j = lane & 15, q = lane >> 4;
     const TileDesc td = p.tiles[tile_idx];
     const bool resumed = SEG && t_begin > 0;
-    f4 *const seg_st = SEG ? p.seg_state + (size_t)tile_idx * (2 * NFW * RC * 256 + 64) : nullptr;
+    f4 *const seg_st = SEG ? p.seg_state + (size_t)(tile_idx - p.n_pinned) * (2 * NFW * RC * 256 + 64) : nullptr;
     const int O = p.O, A = p.A, H = p.H;
     constexpr int XB = RC * CEM_NG * 1024;
     float *part = reinterpret_cast<float *>(smem + 2 * XB);
@@ -635,15 +635,19 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
     cem_rollout_tile<RC, NFW, MODE, false>(p, smem, (int)blockIdx.x, 0, p.H);
 }
 
-// Horizon-segment work queue.  A tile is 16*RC rows for the WHOLE horizon, so a launch whose tile count is not a multiple of
-// the CU count leaves CUs idle while the busiest one finishes (B2: 625 tiles on 256 CUs = 3 on some, 2 on the others: 19 %).
-// Here the launch has one workgroup per (tile, horizon segment) ITEM.  Every workgroup draws a ticket: tickets below n_tiles
-// are the tiles' first segments; a later ticket takes the next entry of a FIFO of tiles whose previous segment has finished
-// (waiting for the entry to be written if need be).  The hardware starts the later workgroups where slots free up, i.e. on
-// the CUs that finished their items first, so a tile's segments drift to the less loaded CUs and the busiest CU no longer
-// carries a whole extra tile.  Deadlock-free for any residency: FIFO entry e is written when the e-th non-final item
-// completes; if every resident workgroup were waiting, all drawn tickets below the FIFO tail would be complete and the
-// number of completed final segments would equal n_tiles — then the tail is n_items and nobody waits.
+// Pinned tiles + floating segments.  A tile is 16*RC rows for the WHOLE horizon, so a launch whose tile count is not a multiple
+// of the CU count leaves CUs idle while the busiest one finishes (B2: 625 tiles on 256 CUs = 3 on some, 2 on the others: 19 %).
+// Here the first n_pinned tiles (a multiple of the CU count: the same number on every CU) run as before, one workgroup each
+// for the whole horizon.  The remaining "floating" tiles are cut into horizon segments, one workgroup per (tile, segment)
+// item: every floating workgroup draws a ticket; tickets below n_float are the floaters' first segments, a later ticket takes
+// the next entry of a FIFO of floaters whose previous segment has finished (waiting for the entry to be written if need be).
+// The hardware starts a floating workgroup in whatever slot is free, so a floater's segments visit the CUs whose spare slot
+// has been idle longest, and every CU ends up carrying the same share of the floaters' work.  Floating workgroups run at
+// raised issue priority: a floater is a 30-step dependent chain that always shares its CU with the pinned tiles, and would
+// otherwise finish last.  State crosses segments through p.seg_state; results are bit-identical to the plain launch.
+// Deadlock-free for any residency: pinned workgroups wait for nothing; FIFO entry e is written when the e-th non-final
+// floating item completes; if every resident floating workgroup were waiting, all drawn tickets below the FIFO tail would be
+// complete and the number of completed final segments would equal n_float — then the tail is the item count and nobody waits.
 #define CEM_SEG_SPIN_LIMIT (1u << 23)
 template <int RC, int NFW>
 __global__ __launch_bounds__(256) void cem_rollout_seg_kernel(const RolloutParams p)
@@ -651,11 +655,20 @@ __global__ __launch_bounds__(256) void cem_rollout_seg_kernel(const RolloutParam
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t item_s;
     if (p.check_done && p.ctrl->done) return;
+    if ((int)blockIdx.x < p.n_pinned) {
+        cem_rollout_tile<RC, NFW, 0, true>(p, smem, (int)blockIdx.x, 0, p.H);
+        return;
+    }
+#ifndef CEM_FLOAT_PRIO
+#define CEM_FLOAT_PRIO 3
+#endif
+    __builtin_amdgcn_s_setprio(CEM_FLOAT_PRIO);
+    const uint32_t n_float = (uint32_t)(p.n_tiles - p.n_pinned);
     if (threadIdx.x == 0) {
         const uint32_t ticket = atomicAdd(p.seg_queue, 1u);
-        uint32_t item = ticket << 8;                       // (tile << 8) | segment
-        if (ticket >= (uint32_t)p.n_tiles) {
-            const uint32_t *slot = p.seg_flags + (ticket - (uint32_t)p.n_tiles);
+        uint32_t item = (((uint32_t)p.n_pinned + ticket) << 8);      // (tile << 8) | segment
+        if (ticket >= n_float) {
+            const uint32_t *slot = p.seg_flags + (ticket - n_float);
             uint32_t spins = 0, v;
             while ((v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && ++spins < CEM_SEG_SPIN_LIMIT)
                 __builtin_amdgcn_s_sleep(16);

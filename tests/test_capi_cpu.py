@@ -168,9 +168,13 @@ def test_tile_size_choice_follows_the_measured_cost_model(built_lib):
 
 
 def test_horizon_segments_are_chosen_where_tiles_do_not_divide_the_cus(built_lib):
-    # B2: 625 one-chunk tiles on 256 CUs (3 on the busiest, 2.44 mean): the work queue of (tile, 5-step) items evens that out
+    # B2: 625 one-chunk tiles on 256 CUs (3 on the busiest, 2.44 mean): 512 stay whole, 113 float in six 5-step segments
     assert plan_segments(_cfg()) == (6, 5)
     assert plan_tiles(_cfg())[0] == 1
+    # one pinned tile per CU (375 tiles) or a remainder that nearly fills the CUs (750 tiles): measured no gain -> not used
+    assert plan_segments(_cfg(n_samples=1200, n_elite=120))[0] == 1
+    assert plan_segments(_cfg(n_samples=2400, n_elite=240))[0] == 1
+    assert plan_segments(_cfg(n_samples=1800, n_elite=180))[0] == 6          # 563 tiles: 2.2 per CU
     # B1 (157 tiles: at most one per CU), B3 / B4 (tile counts that are multiples of 256): one workgroup per tile, as before
     assert plan_segments(_cfg(n_samples=500, horizon=25, n_elite=50))[0] == 1
     assert plan_segments(_cfg(ensemble_size=16, particles=16, n_samples=8192, n_elite=819))[0] == 1
