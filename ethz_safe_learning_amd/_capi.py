@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     'cem_planner_set_normaliser', 'cem_planner_plan', 'cem_plan_begin', 'cem_plan_rollout', 'cem_plan_select',
     'cem_plan_end', 'cem_comm_unique_id', 'cem_planner_comm_init', 'cem_planner_comm_destroy', 'cem_plan_exchange', 'cem_planner_graph_status', 'cem_unfold_sequences', 'cem_compute_objective', 'cem_scorer_reward', 'cem_scorer_cost', 'cem_fill_noise', 'cem_planner_set_timing', 'cem_planner_last_timing',
     'cem_trainer_workspace_bytes', 'cem_trainer_blob_floats', 'cem_trainer_create', 'cem_trainer_destroy', 'cem_trainer_set_state',
-    'cem_trainer_get_state', 'cem_trainer_step', 'cem_trainer_eval',
+    'cem_trainer_get_state', 'cem_trainer_step', 'cem_trainer_steps', 'cem_trainer_eval',
 ]
 
 
@@ -131,6 +131,7 @@ def load():
     lib.cem_trainer_set_state.argtypes = [vp, vp, vp, vp]
     lib.cem_trainer_get_state.argtypes = [vp, vp, vp, vp]
     lib.cem_trainer_step.argtypes = [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_float, vp]
+    lib.cem_trainer_steps.argtypes = [vp, vp, vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
     lib.cem_trainer_eval.argtypes = [vp, vp, vp, C.c_int32, fp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)          # raises AttributeError if the symbol is not exported

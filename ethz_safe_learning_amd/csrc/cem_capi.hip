@@ -1120,7 +1120,7 @@ struct cem_trainer {
     cem_train_config_t cfg;
     char *ws; hipStream_t stream; bool own_stream;
     size_t nat, scratch_pm;
-    size_t oW, oM, oV, oG, oS, oL, oT, total;
+    size_t oW, oM, oV, oG, oS, oL, oP, oT, total;
 };
 
 namespace {
@@ -1140,11 +1140,12 @@ void train_layout(cem_trainer *t)
 {
     const cem_train_config_t &c = t->cfg;
     t->nat = train_nat(&c);
-    t->scratch_pm = (size_t)(c.n_layers + 8) * CEM_TB * c.units;
+    t->scratch_pm = (size_t)(c.n_layers + 8) * CEM_TROWS * c.units;      // per (member, row part) workgroup
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
     t->oW = take(t->nat * c.ensemble_size * 4); t->oM = take(t->nat * c.ensemble_size * 4); t->oV = take(t->nat * c.ensemble_size * 4);
-    t->oG = take(t->nat * c.ensemble_size * 4); t->oS = take(t->scratch_pm * c.ensemble_size * 4); t->oL = take((size_t)c.ensemble_size * 2 * 4);
+    t->oG = take(t->nat * c.ensemble_size * CEM_TPARTS * 4); t->oS = take(t->scratch_pm * c.ensemble_size * CEM_TPARTS * 4);
+    t->oL = take((size_t)c.ensemble_size * 4); t->oP = take((size_t)c.ensemble_size * CEM_TPARTS * 2 * 4);
     t->oT = take(32 * sizeof(long long));            // phase stamps of -DCEM_STAMPS diagnostic builds: the LAST 256 B of the workspace
     t->total = o;
 }
@@ -1153,7 +1154,7 @@ void fill_train_params(const cem_trainer *t, TrainParams &p)
     const cem_train_config_t &c = t->cfg;
     std::memset(&p, 0, sizeof(p));
     p.W = (float *)(t->ws + t->oW); p.Mo = (float *)(t->ws + t->oM); p.Vo = (float *)(t->ws + t->oV);
-    p.grad = (float *)(t->ws + t->oG); p.scratch = (float *)(t->ws + t->oS);
+    p.grad = (float *)(t->ws + t->oG); p.scratch = (float *)(t->ws + t->oS); p.loss_part = (float *)(t->ws + t->oP);
     p.D = c.inputs_dim; p.O = c.outputs_dim; p.U = c.units; p.L = c.n_layers; p.E = c.ensemble_size;
     p.nat = (uint32_t)t->nat; p.scratch_per_member = (uint32_t)t->scratch_pm;
     p.beta1 = c.beta1; p.beta2 = c.beta2; p.eps = c.epsilon; p.clip = c.clipvalue;
@@ -1227,7 +1228,7 @@ int cem_trainer_step(cem_trainer_t *t, const float *x_dev, const float *y_dev, c
     if (perm_dev && offset + bt > nperm) return CEM_ERR_INVALID_ARG;
     TrainParams p; fill_train_params(t, p);
     p.x = x_dev; p.y = y_dev; p.perm = perm_dev; p.nperm = nperm; p.offset = offset; p.Bt = bt; p.lr_t = lr_t; p.loss_out = loss_dev; p.train = 1;
-    hipLaunchKernelGGL(cem_train_step_kernel, dim3(t->cfg.ensemble_size), dim3(CEM_TNT), 0, t->stream, p);
+    hipLaunchKernelGGL(cem_train_step_kernel, dim3(t->cfg.ensemble_size * CEM_TPARTS), dim3(CEM_TNT), 0, t->stream, p);
     const size_t n4 = (size_t)p.E * p.nat / 4;
     const unsigned adam_grid = (unsigned)std::min<size_t>(std::max<size_t>((n4 + 255) / 256, 1), 2048);
     hipLaunchKernelGGL(cem_adam_kernel, dim3(adam_grid), dim3(256), 0, t->stream, p);
@@ -1235,21 +1236,34 @@ int cem_trainer_step(cem_trainer_t *t, const float *x_dev, const float *y_dev, c
     return CEM_OK;
 }
 
+int cem_trainer_steps(cem_trainer_t *t, const float *x_dev, const float *y_dev, const int32_t *perm_dev, int32_t nperm, int32_t n_steps,
+                      const int32_t *offsets, const int32_t *bts, const float *lr_ts, float *loss_dev)
+{
+    if (!t || !offsets || !bts || !lr_ts || n_steps < 0) return CEM_ERR_INVALID_ARG;
+    for (int s = 0; s < n_steps; ++s) {
+        const int st = cem_trainer_step(t, x_dev, y_dev, perm_dev, nperm, offsets[s], bts[s], lr_ts[s], loss_dev + (size_t)s * t->cfg.ensemble_size);
+        if (st) return st;
+    }
+    return CEM_OK;
+}
+
 int cem_trainer_eval(cem_trainer_t *t, const float *x_dev, const float *y_dev, int32_t n, float *loss_out)
 {
     if (!t || !x_dev || !y_dev || !loss_out || n < 1) return CEM_ERR_INVALID_ARG;
     const int E = t->cfg.ensemble_size;
-    std::vector<float> sums((size_t)E * 2), part((size_t)E * 2);
+    std::vector<float> sums((size_t)E * 2), part((size_t)E * CEM_TPARTS * 2);
     std::fill(sums.begin(), sums.end(), 0.f);
     TrainParams p; fill_train_params(t, p);
     p.x = x_dev; p.y = y_dev; p.perm = nullptr; p.loss_out = (float *)(t->ws + t->oL); p.train = 0;
     for (int off = 0; off < n; off += t->cfg.batch_size) {
         p.offset = off; p.Bt = std::min(t->cfg.batch_size, n - off);
-        hipLaunchKernelGGL(cem_train_step_kernel, dim3(E), dim3(CEM_TNT), 0, t->stream, p);
+        hipLaunchKernelGGL(cem_train_step_kernel, dim3(E * CEM_TPARTS), dim3(CEM_TNT), 0, t->stream, p);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(part.data(), t->ws + t->oL, part.size() * 4, hipMemcpyDeviceToHost, t->stream));
+        HIPCHK(hipMemcpyAsync(part.data(), t->ws + t->oP, part.size() * 4, hipMemcpyDeviceToHost, t->stream));
         HIPCHK(hipStreamSynchronize(t->stream));
-        for (size_t i = 0; i < sums.size(); ++i) sums[i] += part[i];
+        const int nparts = (p.Bt + CEM_TROWS - 1) / CEM_TROWS;
+        for (int m = 0; m < E; ++m)
+            for (int q = 0; q < nparts; ++q) { sums[2 * m] += part[((size_t)m * CEM_TPARTS + q) * 2]; sums[2 * m + 1] += part[((size_t)m * CEM_TPARTS + q) * 2 + 1]; }
     }
     const double cnt = (double)n * t->cfg.outputs_dim;
     double total = 0;

@@ -2,22 +2,27 @@
 // simba/models/mlp_ensemble.py:134-155, with negative_log_likelihood (:64-67) and
 // tf.keras.optimizers.Adam(lr, clipvalue=1.0, epsilon=1e-5) (:113-117).
 //
-// One workgroup per ensemble member (the members are independent: their own minibatch, weights and Adam moments).
-// A training step is ~28 MFLOP per member in 17 small dependent GEMMs (batch <= 64): latency-bound by construction, so this
-// is a plain LDS-tiled fp32 FMA GEMM (the fp32 MFMA has the same peak rate as the packed vector FMA on gfx950), everything
-// L2 resident.  The workgroup is 512 threads (two waves per SIMD: the partner hides LDS / L2 latency) and its output tile
-// 64 x 128, so every layer is ONE pass over its K dimension.  Weights stay in the Keras layout ([in][out]) the planner's
-// set_weights() consumes.
+// A training step is ~28 MFLOP per member in 14 small dependent GEMMs (batch <= 64): latency-bound by construction.  The
+// members are independent (their own minibatch, weights and Adam moments), and so are the ROWS of a member's minibatch in
+// everything except the weight gradients, which sum over rows.  So a member's step runs on CEM_TPARTS workgroups, each
+// taking CEM_TROWS = 16 of the rows through the forward pass, the loss, and the backward pass; each writes its PARTIAL weight
+// gradients, and the Adam kernel adds the partials in a fixed order before the update (deterministic: no atomics).  15
+// members x 4 parts = 60 workgroups instead of 15, and each GEMM's row dimension is one MFMA block.
+// The GEMM is LDS-tiled on v_mfma_f32_16x16x4_f32, everything L2 resident; the workgroup is 512 threads (two waves per SIMD:
+// the partner hides LDS / L2 latency).  Weights stay in the Keras layout ([in][out]) the planner's set_weights() consumes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #define CEM_TB 64            // max minibatch rows per member (config/models.yaml:4 batch_size: 64)
+#define CEM_TROWS 16         // minibatch rows per workgroup
+#define CEM_TPARTS (CEM_TB / CEM_TROWS)
 
 struct TrainParams {
     float *W, *Mo, *Vo;          // [E][nat] weights, Adam first / second moments (natural blob layout of cem_mpc.h)
-    float *grad;                 // [E][nat]
-    float *scratch;              // [E][scratch_per_member]
+    float *grad;                 // [CEM_TPARTS][E][nat] partial gradients of the row parts
+    float *loss_part;            // [E][CEM_TPARTS][2] partial sums of the loss (log term, squared term)
+    float *scratch;              // [E * CEM_TPARTS][scratch_per_member]
     const float *x, *y;          // [n][D] scaled inputs, [n][O] targets (next_obs - obs)
     const int32_t *perm;         // [E][nperm] bootstrap shuffles (mlp_ensemble.py:172-173) or nullptr (rows offset.. directly)
     int32_t nperm, offset, Bt;
@@ -47,7 +52,8 @@ struct TrainParams {
 #define CEM_TM 64
 #define CEM_TN 128
 #define CEM_TPAD 16                                     // row stride = 16 (mod 64) words: the 4 k-rows of an MFMA operand read hit disjoint banks
-#define CEM_TRAIN_LDS_FLOATS (2 * CEM_TK * (CEM_TM + CEM_TPAD) + 2 * CEM_TK * (CEM_TN + CEM_TPAD))
+#define CEM_TKMAX 128                                   // the deepest K a 16-row GEMM stages in ONE shot (units, 2 * outputs_dim <= 128)
+#define CEM_TRAIN_LDS_FLOATS (CEM_TKMAX * (CEM_TM + CEM_TPAD) + CEM_TKMAX * (CEM_TN + CEM_TPAD))   // the one-shot 16-row form is the largest (112 KB)
 // the workgroup's GEMM staging tiles (also the scratch of the small reductions between GEMMs); file scope so that the
 // non-inlined GEMM addresses it as LDS
 __shared__ __attribute__((aligned(16))) float g_train_lds[CEM_TRAIN_LDS_FLOATS];
@@ -66,6 +72,8 @@ struct GemmEpi {
     // optional column split (the mu | variance head pair as ONE GEMM): columns n >= nsplit go to out1 / bias1 at n - nsplit
     gptr out1; gcptr bias1;
     long long *st;         // -DCEM_STAMPS builds: accumulates [8] prologue (first slab in LDS), [9] k loop, [10] epilogue cycles of member 0
+    // optional: column sums of B over its K rows (K <= one slab), i.e. the bias gradient sum_r dh[r][n] next to dW = h^T dh
+    gptr colsum, colsum1;  // columns n >= nsplit go to colsum1[n - nsplit]
 };
 
 // operand split of the fused head GEMMs: B(k, n) comes from B1 at (k - ksplit, n) for k >= ksplit or at (k, n - nsplit) for
@@ -73,32 +81,41 @@ struct GemmEpi {
 struct GemmSplit { gcptr A1, B1; int ksplit, nsplit; };
 #define CEM_NOSPLIT GemmSplit{nullptr, nullptr, 0x7fffffff, 0x7fffffff}
 
-__device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, const int K, const gcptr Ag, const int sam, const int sak,
-                                                  const gcptr Bg, const int sbk, const int sbn, const GemmEpi e, const GemmSplit sp)
+// Tile forms (TMODE).  0: 64 x 128 output tile, waves = 4 row blocks x 2 groups of 64 columns.  1 (R16): the output has at most
+// 16 rows (a row part's activations): the eight waves take eight 16-column groups of ONE row block.  2 (M128): 128 x 128 output
+// tile, every wave two row blocks x four column blocks — the weight-gradient GEMMs (K = the part's 16 rows) in one pass.
+template <int TMODE>
+__device__ __attribute__((noinline)) void wg_gemm_t(const int M, const int N, const int K, const gcptr Ag, const int sam, const int sak,
+                                                    const gcptr Bg, const int sbk, const int sbn, const GemmEpi e, const GemmSplit sp)
 {
+    constexpr bool R16 = TMODE == 1;
+    constexpr int NCB = R16 ? 1 : CEM_NCB;
+    constexpr int NRB = TMODE == 2 ? 2 : 1;                                        // row blocks per wave
+    constexpr int TM = TMODE == 2 ? 2 * CEM_TM : CEM_TM;
     float *lds = g_train_lds;
-    typedef float TileA[CEM_TK][CEM_TM + CEM_TPAD];
+    typedef float TileA[CEM_TK][TM + CEM_TPAD];
     typedef float TileB[CEM_TK][CEM_TN + CEM_TPAD];
     TileA *As = reinterpret_cast<TileA *>(lds);                                    // As[buf][k][m]
-    TileB *Bs = reinterpret_cast<TileB *>(lds + 2 * CEM_TK * (CEM_TM + CEM_TPAD));   // Bs[buf][k][n]
-    constexpr int NEA = CEM_TM * CEM_TK / CEM_TNT, NEB = CEM_TN * CEM_TK / CEM_TNT;   // elements per thread per operand slab
-    // MFMA 16x16x4 core: wave w owns rows [16 rb, +16) x columns [64 ch, +64) of the tile as four 16x16 blocks; lane (kq, i)
-    // feeds A[16 rb + i][4P + kq] and B[4P + kq][64 ch + 16 cb + i]; the block's D has rows 4 kq + r, column i on the lane.
-    // Each loaded operand word serves 16 FMAs (4x4 micro-tiles: 2), which takes the kernel off the LDS-bandwidth bound; the
-    // hardware accumulates k in ascending order, the same chain the FMA version ran.
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, rb = wv & 3, ch = wv >> 2, kq = lane >> 4, li = lane & 15;
-    constexpr int CW = 16 * CEM_NCB;                                               // columns per wave
+    TileB *Bs = reinterpret_cast<TileB *>(lds + 2 * CEM_TK * (TM + CEM_TPAD));       // Bs[buf][k][n]
+    constexpr int NEA = TM * CEM_TK / CEM_TNT, NEB = CEM_TN * CEM_TK / CEM_TNT;       // elements per thread per operand slab
+    // MFMA 16x16x4 core: wave w owns rows [16 rb, +16) (+64 for its second row block) x columns [CW ch, +CW) of the tile as 16x16
+    // blocks; lane (kq, i) feeds A[16 rb + i][4P + kq] and B[4P + kq][CW ch + 16 cb + i]; the block's D has rows 4 kq + r, column i
+    // on the lane.  Each loaded operand word serves 16 FMAs; the hardware accumulates k in ascending order.
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, rb = R16 ? 0 : (wv & 3), ch = R16 ? wv : (wv >> 2), kq = lane >> 4, li = lane & 15;
+    constexpr int CW = 16 * NCB;                                                   // columns per wave
     const int nk = (K + CEM_TK - 1) / CEM_TK;
-    for (int m0 = 0; m0 < M; m0 += CEM_TM) {
+    for (int m0 = 0; m0 < M; m0 += TM) {
         for (int n0 = 0; n0 < N; n0 += CEM_TN) {
             typedef float f4v __attribute__((ext_vector_type(4)));
-            f4v acc[CEM_NCB];                             // acc[cb][r] = C[16 rb + 4 kq + r][CW ch + 16 cb + li]
+            f4v acc[NRB][NCB];                        // acc[rk][cb][r] = C[16 rb + 64 rk + 4 kq + r][CW ch + 16 cb + li]
 #pragma unroll
-            for (int cb = 0; cb < CEM_NCB; ++cb) acc[cb] = (f4v){0.f, 0.f, 0.f, 0.f};
+            for (int rk = 0; rk < NRB; ++rk)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[rk][cb] = (f4v){0.f, 0.f, 0.f, 0.f};
             float ra[NEA], rbuf[NEB];
             auto a_idx = [&](const int q, int &mm, int &kk) {
                 const int el = tid + CEM_TNT * q;
-                if (sak == 1) { kk = el % CEM_TK; mm = el / CEM_TK; } else { mm = el % CEM_TM; kk = el / CEM_TM; }   // coalesce along the unit stride
+                if (sak == 1) { kk = el % CEM_TK; mm = el / CEM_TK; } else { mm = el % TM; kk = el / TM; }   // coalesce along the unit stride
             };
             auto b_idx = [&](const int q, int &nn, int &kb) {
                 const int el = tid + CEM_TNT * q;
@@ -144,34 +161,48 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
 #ifdef CEM_STAMPS
             long long t1_ = (long long)__builtin_amdgcn_s_memtime();
 #endif
+            // bias gradient riding on the weight-gradient GEMM: the whole K (<= one slab) of B sits in LDS buffer 0 (rows >= K are
+            // zero); one thread per column adds its K values in row order
+            if (e.colsum && m0 == 0 && tid < CEM_TN && n0 + tid < N) {
+                float t = 0.f;
+#pragma unroll 8
+                for (int k = 0; k < CEM_TK; ++k) t = t + Bs[0][k][tid];
+                const int n = n0 + tid;
+                (n < sp.nsplit ? e.colsum : e.colsum1)[n < sp.nsplit ? n : n - sp.nsplit] = t;
+            }
             // epilogue operands, requested now (batched, clamped indices) so that their latency hides behind the k loop
-            float bia[CEM_NCB], gat[4][CEM_NCB];
+            float bia[NCB], gat[NRB][4][NCB];
 #pragma unroll
-            for (int jn = 0; jn < CEM_NCB; ++jn) {
+            for (int jn = 0; jn < NCB; ++jn) {
                 const int n = n0 + CW * ch + 16 * jn + li, cn = n < N ? n : N - 1;
                 const gcptr bp = cn < sp.nsplit ? e.bias : e.bias1;
                 bia[jn] = e.bias ? bp[cn < sp.nsplit ? cn : cn - sp.nsplit] : 0.f;
             }
             if (e.gate) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int rk = 0; rk < NRB; ++rk)
 #pragma unroll
-                    for (int jn = 0; jn < CEM_NCB; ++jn) {
-                        const int mI = m0 + 16 * rb + 4 * kq + i, n = n0 + CW * ch + 16 * jn + li;
-                        gat[i][jn] = e.gate[(mI < M ? mI : M - 1) * e.ldg + (n < N ? n : N - 1)];
-                    }
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < NCB; ++jn) {
+                            const int mI = m0 + 16 * rb + 64 * rk + 4 * kq + i, n = n0 + CW * ch + 16 * jn + li;
+                            gat[rk][i][jn] = e.gate[(mI < M ? mI : M - 1) * e.ldg + (n < N ? n : N - 1)];
+                        }
             }
             for (int kt = 0; kt < nk; ++kt) {
                 const int buf = kt & 1;
                 if (kt + 1 < nk) fetch((kt + 1) * CEM_TK);
 #pragma unroll
                 for (int P = 0; P < CEM_TK / 4; ++P) {
-                    const float a = As[buf][4 * P + kq][16 * rb + li];
-                    float b[CEM_NCB];
+                    float a[NRB], b[NCB];
 #pragma unroll
-                    for (int cb = 0; cb < CEM_NCB; ++cb) b[cb] = Bs[buf][4 * P + kq][CW * ch + 16 * cb + li];
+                    for (int rk = 0; rk < NRB; ++rk) a[rk] = As[buf][4 * P + kq][16 * rb + 64 * rk + li];
 #pragma unroll
-                    for (int cb = 0; cb < CEM_NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[cb], acc[cb], 0, 0, 0);
+                    for (int cb = 0; cb < NCB; ++cb) b[cb] = Bs[buf][4 * P + kq][CW * ch + 16 * cb + li];
+#pragma unroll
+                    for (int rk = 0; rk < NRB; ++rk)
+#pragma unroll
+                        for (int cb = 0; cb < NCB; ++cb) acc[rk][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rk], b[cb], acc[rk][cb], 0, 0, 0);
                 }
                 if (kt + 1 < nk) stash(buf ^ 1);
                 __syncthreads();
@@ -181,22 +212,154 @@ __device__ __attribute__((noinline)) void wg_gemm(const int M, const int N, cons
 #endif
             // epilogue (its bias / gate operands were requested before the k loop)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int rk = 0; rk < NRB; ++rk)
 #pragma unroll
-                for (int jn = 0; jn < CEM_NCB; ++jn) {
-                    const int mI = m0 + 16 * rb + 4 * kq + i, n = n0 + CW * ch + 16 * jn + li;
-                    float v = acc[jn][i];
-                    if (e.bias) v = v + bia[jn];
-                    if (e.relu) v = fmaxf(v, 0.f);
-                    if (e.gate) v = gat[i][jn] > 0.f ? v : 0.f;
-                    if (mI < M && n < N) (n < sp.nsplit ? e.out : e.out1)[(mI < M ? mI : M - 1) * e.ldo + (n < sp.nsplit ? n : n - sp.nsplit)] = v;
-                }
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < NCB; ++jn) {
+                        const int mI = m0 + 16 * rb + 64 * rk + 4 * kq + i, n = n0 + CW * ch + 16 * jn + li;
+                        float v = acc[rk][jn][i];
+                        if (e.bias) v = v + bia[jn];
+                        if (e.relu) v = fmaxf(v, 0.f);
+                        if (e.gate) v = gat[rk][i][jn] > 0.f ? v : 0.f;
+                        if (mI < M && n < N) (n < sp.nsplit ? e.out : e.out1)[(mI < M ? mI : M - 1) * e.ldo + (n < sp.nsplit ? n : n - sp.nsplit)] = v;
+                    }
 #ifdef CEM_STAMPS
             if (e.st && blockIdx.x == 0 && tid == 0) { const long long t3_ = (long long)__builtin_amdgcn_s_memtime(); e.st[8] += t1_ - t0_; e.st[9] += t2_ - t1_; e.st[10] += t3_ - t2_; e.st[11] += 1; }
 #endif
         }
     }
     __syncthreads();
+}
+
+// One-shot form of the 16-row GEMMs (forward layers, heads, dh: M <= 16, N <= 128, K <= 128).  With 16 rows a k slab is eight
+// MFMAs per wave — nothing to hide an L2 round trip behind — so the slab pipeline above degenerates into K/32 serial round
+// trips.  Here every thread issues ALL its operand loads at once (36 words), the whole A [K][16] and B [K][128] go to LDS
+// behind one barrier, and the k loop runs uninterrupted.
+__device__ __attribute__((noinline)) void wg_gemm_r16_deep(const int M, const int N, const int K, const gcptr Ag, const int sam, const int sak,
+                                                         const gcptr Bg, const int sbk, const int sbn, const GemmEpi e, const GemmSplit sp)
+{
+    float *lds = g_train_lds;
+    typedef float RowA[CEM_TM + CEM_TPAD];
+    typedef float RowB[CEM_TN + CEM_TPAD];
+    RowA *As = reinterpret_cast<RowA *>(lds);                                      // As[k][m], m < 16 used
+    RowB *Bs = reinterpret_cast<RowB *>(lds + CEM_TKMAX * (CEM_TM + CEM_TPAD));      // Bs[k][n]
+    constexpr int NEA = 16 * CEM_TKMAX / CEM_TNT, NEB = CEM_TN * CEM_TKMAX / CEM_TNT;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, kq = lane >> 4, li = lane & 15;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    float ra[NEA], rbuf[NEB];
+    auto a_idx = [&](const int q, int &mm, int &kk) {
+        const int el = tid + CEM_TNT * q;
+        if (sak == 1) { kk = el % CEM_TKMAX; mm = el / CEM_TKMAX; } else { mm = el % 16; kk = el / 16; }
+    };
+    auto b_idx = [&](const int q, int &nn, int &kb) {
+        const int el = tid + CEM_TNT * q;
+        if (sbn == 1) { nn = el % CEM_TN; kb = el / CEM_TN; } else { kb = el % CEM_TKMAX; nn = el / CEM_TKMAX; }
+    };
+#ifdef CEM_STAMPS
+    long long t0_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+    for (int q = 0; q < NEA; ++q) {
+        int mm, kk; a_idx(q, mm, kk);
+        const int cm = mm < M ? mm : M - 1, ck = kk < K ? kk : K - 1;
+        const bool a0 = ck < sp.ksplit;
+        const gcptr ap = a0 ? Ag : sp.A1;
+        ra[q] = ap[cm * sam + (a0 ? ck : ck - sp.ksplit) * sak];
+    }
+    // a row-major B (the forward GEMMs: W[k][n]) in 16-byte loads and 16-byte LDS stores where N, the row stride and the split
+    // point are multiples of 4 words and the operands 16-byte aligned: a quarter of the load / store instructions
+    typedef float f4v_ __attribute__((ext_vector_type(4)));
+#ifdef CEM_TRAIN_NOQUADS       // diagnostic A/B build
+    const bool quads = false;
+#else
+    const bool quads = sbn == 1 && sbk % 4 == 0 && N % 4 == 0 && (sp.nsplit >= N || sp.nsplit % 4 == 0) &&
+                       ((reinterpret_cast<uintptr_t>(Bg) | reinterpret_cast<uintptr_t>(sp.B1 ? sp.B1 : Bg)) & 15) == 0;
+#endif
+    auto bq_idx = [&](const int q, int &nn, int &kb) {     // first element of quad q of this thread
+        const int el = tid + CEM_TNT * q;
+        nn = (el % (CEM_TN / 4)) * 4; kb = el / (CEM_TN / 4);
+    };
+    if (quads) {
+#pragma unroll
+        for (int q = 0; q < NEB / 4; ++q) {
+            int nn, kb; bq_idx(q, nn, kb);
+            // clamp the quad as a whole (N, K and the split points are multiples of 4 here)
+            const int cn = nn < N ? nn : N - 4, ck = kb < K ? kb : K - 1;
+            const gcptr bp = (ck < sp.ksplit && cn < sp.nsplit) ? Bg : sp.B1;
+            const f4v_ v = *reinterpret_cast<const __attribute__((address_space(1))) f4v_ *>(
+                bp + (ck < sp.ksplit ? ck : ck - sp.ksplit) * sbk + (cn < sp.nsplit ? cn : cn - sp.nsplit) * sbn);
+            rbuf[4 * q] = v[0]; rbuf[4 * q + 1] = v[1]; rbuf[4 * q + 2] = v[2]; rbuf[4 * q + 3] = v[3];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NEB; ++q) {
+            int nn, kb; b_idx(q, nn, kb);
+            const int cn = nn < N ? nn : N - 1, ck = kb < K ? kb : K - 1;
+            const gcptr bp = (ck < sp.ksplit && cn < sp.nsplit) ? Bg : sp.B1;
+            rbuf[q] = bp[(ck < sp.ksplit ? ck : ck - sp.ksplit) * sbk + (cn < sp.nsplit ? cn : cn - sp.nsplit) * sbn];
+        }
+    }
+    // epilogue operands ride in the same round trip
+    const int n = 16 * wv + li, cn = n < N ? n : N - 1;
+    float bia = 0.f, gat[4];
+    if (e.bias) { const gcptr bp = cn < sp.nsplit ? e.bias : e.bias1; bia = bp[cn < sp.nsplit ? cn : cn - sp.nsplit]; }
+    if (e.gate) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int mI = 4 * kq + i; gat[i] = e.gate[(mI < M ? mI : M - 1) * e.ldg + cn]; }
+    }
+#pragma unroll
+    for (int q = 0; q < NEA; ++q) { int mm, kk; a_idx(q, mm, kk); As[kk][mm] = (mm < M && kk < K) ? ra[q] : 0.f; }
+    if (quads) {
+#pragma unroll
+        for (int q = 0; q < NEB / 4; ++q) {
+            int nn, kb; bq_idx(q, nn, kb);
+            const bool ok = nn < N && kb < K;           // N is a multiple of 4: a quad is inside or outside as a whole
+            *reinterpret_cast<f4v_ *>(&Bs[kb][nn]) = ok ? (f4v_){rbuf[4 * q], rbuf[4 * q + 1], rbuf[4 * q + 2], rbuf[4 * q + 3]} : (f4v_){0.f, 0.f, 0.f, 0.f};
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NEB; ++q) { int nn, kb; b_idx(q, nn, kb); Bs[kb][nn] = (nn < N && kb < K) ? rbuf[q] : 0.f; }
+    }
+    __syncthreads();
+#ifdef CEM_STAMPS
+    long long t1_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    if (e.colsum && tid < N) {                             // bias gradient next to a weight gradient with few rows (inputs_dim <= 16)
+        float t = 0.f;
+        for (int k = 0; k < K; ++k) t = t + Bs[k][tid];
+        (tid < sp.nsplit ? e.colsum : e.colsum1)[tid < sp.nsplit ? tid : tid - sp.nsplit] = t;
+    }
+    f4v acc = (f4v){0.f, 0.f, 0.f, 0.f};
+    const int nP = (K + 3) / 4;
+#pragma unroll 8
+    for (int P = 0; P < nP; ++P)                           // ascending k: the same accumulation chain as the slab form
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(As[4 * P + kq][li], Bs[4 * P + kq][16 * wv + li], acc, 0, 0, 0);
+#ifdef CEM_STAMPS
+    long long t2_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int mI = 4 * kq + i;
+        float v = acc[i];
+        if (e.bias) v = v + bia;
+        if (e.relu) v = fmaxf(v, 0.f);
+        if (e.gate) v = gat[i] > 0.f ? v : 0.f;
+        if (mI < M && n < N) (n < sp.nsplit ? e.out : e.out1)[mI * e.ldo + (n < sp.nsplit ? n : n - sp.nsplit)] = v;
+    }
+#ifdef CEM_STAMPS
+    if (e.st && blockIdx.x == 0 && tid == 0) { const long long t3_ = (long long)__builtin_amdgcn_s_memtime(); e.st[8] += t1_ - t0_; e.st[9] += t2_ - t1_; e.st[10] += t3_ - t2_; e.st[11] += 1; }
+#endif
+    __syncthreads();
+}
+
+__device__ __forceinline__ void wg_gemm(const int M, const int N, const int K, const gcptr Ag, const int sam, const int sak,
+                                        const gcptr Bg, const int sbk, const int sbn, const GemmEpi e, const GemmSplit sp)
+{
+    if (M <= 16 && N <= CEM_TN && K <= CEM_TKMAX) wg_gemm_r16_deep(M, N, K, Ag, sam, sak, Bg, sbk, sbn, e, sp);
+    else if (M <= 16) wg_gemm_t<1>(M, N, K, Ag, sam, sak, Bg, sbk, sbn, e, sp);
+    else if (M > CEM_TM && K <= CEM_TK) wg_gemm_t<2>(M, N, K, Ag, sam, sak, Bg, sbk, sbn, e, sp);
+    else wg_gemm_t<0>(M, N, K, Ag, sam, sak, Bg, sbk, sbn, e, sp);
 }
 
 __device__ __forceinline__ float train_softplus(float x)         // Eigen's three branches, precise
@@ -242,20 +405,24 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
 {
     float *lds = g_train_lds;
     __shared__ float red[CEM_TNT / 64];
-    const int m = blockIdx.x, tid = threadIdx.x;
-    const int D = p.D, O = p.O, U = p.U, L = p.L, Bt = p.Bt;
-    float *W = p.W + (size_t)m * p.nat, *G = p.grad + (size_t)m * p.nat;
-    float *sc = p.scratch + (size_t)m * p.scratch_per_member;
+    // workgroup = (member m, row part): rows [part * CEM_TROWS, +Bt) of the member's minibatch of p.Bt rows
+    const int m = blockIdx.x / CEM_TPARTS, part = blockIdx.x % CEM_TPARTS, tid = threadIdx.x;
+    const int D = p.D, O = p.O, U = p.U, L = p.L;
+    const int row0 = part * CEM_TROWS;
+    const int Bt = p.Bt - row0 < CEM_TROWS ? p.Bt - row0 : CEM_TROWS;
+    if (Bt <= 0) return;                          // a short minibatch: the Adam kernel only adds the parts that exist
+    float *W = p.W + (size_t)m * p.nat, *G = p.grad + ((size_t)part * p.E + m) * p.nat;
+    float *sc = p.scratch + (size_t)blockIdx.x * p.scratch_per_member;
     // scratch carve (row stride U for every activation matrix; D, O <= U)
-    float *xs = sc;                              // [TB][U]   h_0
-    float *hs = xs + CEM_TB * U;                 // [L][TB][U] h_1..h_L
-    float *mu = hs + (size_t)L * CEM_TB * U;     // [TB][U]
-    float *vp = mu + CEM_TB * U;
-    float *ys = vp + CEM_TB * U;
-    float *dmu = ys + CEM_TB * U;
-    float *dv = dmu + CEM_TB * U;
-    float *dha = dv + CEM_TB * U;
-    float *dhb = dha + CEM_TB * U;
+    float *xs = sc;                              // [TROWS][U]   h_0
+    float *hs = xs + CEM_TROWS * U;              // [L][TROWS][U] h_1..h_L
+    float *mu = hs + (size_t)L * CEM_TROWS * U;  // [TROWS][U]
+    float *vp = mu + CEM_TROWS * U;
+    float *ys = vp + CEM_TROWS * U;
+    float *dmu = ys + CEM_TROWS * U;
+    float *dv = dmu + CEM_TROWS * U;
+    float *dha = dv + CEM_TROWS * U;
+    float *dhb = dha + CEM_TROWS * U;
     // natural-blob offsets (cem_mpc.h): W_0,b_0,...,W_mu,b_mu,W_var,b_var
     auto offW = [&](int l) { return l == 0 ? (size_t)0 : (size_t)D * U + U + (size_t)(l - 1) * ((size_t)U * U + U); };
     auto offb = [&](int l) { return offW(l) + (size_t)(l == 0 ? D : U) * U; };
@@ -266,10 +433,10 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
 #ifdef CEM_STAMPS
     if (blockIdx.x == 0 && threadIdx.x == 0) { p.stamps[8] = p.stamps[9] = p.stamps[10] = p.stamps[11] = 0; }
 #endif
-    // ---- gather the minibatch ---------------------------------------------------------------------------------
+    // ---- gather this part's rows of the minibatch ---------------------------------------------------------------
     {
         int32_t *rows = reinterpret_cast<int32_t *>(lds);
-        if (tid < Bt) rows[tid] = p.perm ? p.perm[(size_t)m * p.nperm + p.offset + tid] : p.offset + tid;
+        if (tid < Bt) rows[tid] = p.perm ? p.perm[(size_t)m * p.nperm + p.offset + row0 + tid] : p.offset + row0 + tid;
         __syncthreads();
         wg_map<float2>(Bt * U,
             [&](int e) { const int r = e / U, c = e % U; const int row = rows[r];
@@ -281,20 +448,20 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
     CEM_TR_STAMP(1);
     // ---- forward (mlp_ensemble.py:18-22,33-34,59-61) -----------------------------------------------------------
     for (int l = 0; l < L; ++l) {
-        const float *hin = l == 0 ? xs : hs + (size_t)(l - 1) * CEM_TB * U;
-        float *hout = hs + (size_t)l * CEM_TB * U;
+        const float *hin = l == 0 ? xs : hs + (size_t)(l - 1) * CEM_TROWS * U;
+        float *hout = hs + (size_t)l * CEM_TROWS * U;
         const float *Wl = W + offW(l), *bl = W + offb(l);
-        wg_gemm(Bt, U, l == 0 ? D : U, (gcptr)hin, U, 1, (gcptr)Wl, U, 1, GemmEpi{(gptr)hout, U, (gcptr)bl, nullptr, 0, 1, nullptr, nullptr, p.stamps}, CEM_NOSPLIT);     // relu(h W + b)
+        wg_gemm(Bt, U, l == 0 ? D : U, (gcptr)hin, U, 1, (gcptr)Wl, U, 1, GemmEpi{(gptr)hout, U, (gcptr)bl, nullptr, 0, 1, nullptr, nullptr, p.stamps, nullptr, nullptr}, CEM_NOSPLIT);     // relu(h W + b)
     }
     CEM_TR_STAMP(2);
-    const float *hL = hs + (size_t)(L - 1) * CEM_TB * U;
+    const float *hL = hs + (size_t)(L - 1) * CEM_TROWS * U;
     // both heads as ONE GEMM: columns [0, O) = mu head, [O, 2O) = variance head (2O <= 128 fills the tile two N = O GEMMs half use)
     wg_gemm(Bt, 2 * O, U, (gcptr)hL, U, 1, (gcptr)(W + oWmu), O, 1,
-            GemmEpi{(gptr)mu, U, (gcptr)(W + obmu), nullptr, 0, 0, (gptr)vp, (gcptr)(W + obv), p.stamps}, GemmSplit{nullptr, (gcptr)(W + oWv), 0x7fffffff, O});
+            GemmEpi{(gptr)mu, U, (gcptr)(W + obmu), nullptr, 0, 0, (gptr)vp, (gcptr)(W + obv), p.stamps, nullptr, nullptr}, GemmSplit{nullptr, (gcptr)(W + oWv), 0x7fffffff, O});
     CEM_TR_STAMP(3);
     // ---- negative_log_likelihood (:64-67) and its gradient w.r.t. mu and the pre-softplus variance -----------------
     float s_log = 0.f, s_sq = 0.f;
-    const float ninv = 1.0f / ((float)Bt * (float)O * (float)p.E);
+    const float ninv = 1.0f / ((float)p.Bt * (float)O * (float)p.E);          // the mean runs over the WHOLE minibatch (mlp_ensemble.py:64-67)
     wg_map<float3>(Bt * O,
         [&](int e) { const int r = e / O, c = e % O; return make_float3(vp[r * U + c], mu[r * U + c], ys[r * U + c]); },
         [&](int e, float3 in) {
@@ -312,55 +479,29 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
     s_log = block_sum(s_log, red);
     s_sq = block_sum(s_sq, red);
     CEM_TR_STAMP(4);
-    if (!p.train) {
-        if (tid == 0) { p.loss_out[2 * m] = s_log; p.loss_out[2 * m + 1] = s_sq; }
-        return;
-    }
-    if (tid == 0) p.loss_out[m] = (0.5f * s_log / ((float)Bt * (float)O) + 0.5f * s_sq / ((float)Bt * (float)O)) / (float)p.E;
+    // this part's share of the two sums of the loss; the Adam kernel (training) or the host (validation) adds the parts in order
+    if (tid == 0) { p.loss_part[((size_t)m * CEM_TPARTS + part) * 2] = s_log; p.loss_part[((size_t)m * CEM_TPARTS + part) * 2 + 1] = s_sq; }
+    if (!p.train) return;
     __syncthreads();
 
     CEM_TR_STAMP(5);
     // ---- backward ------------------------------------------------------------------------------------------------
-    // column sums (bias gradients) of a [Bt][U]-strided matrix: CEM_TNT/128 partial sums over interleaved rows, added in order
-    float *colred = lds;
-    auto col_sums = [&](const float *src, const int ncol, float *dst) {
-        constexpr int NP = CEM_TNT / 128;
-        for (int c0 = 0; c0 < ncol; c0 += 128) {
-            const int c = c0 + (tid & 127), part = tid >> 7;
-            float a = 0.f;
-            if (c < ncol) {
-#pragma unroll 8
-                for (int r = part; r < Bt; r += NP) a += src[r * U + c];
-            }
-            colred[tid] = a;
-            __syncthreads();
-            if (tid < 128 && c < ncol) {
-                float t = colred[tid];
-#pragma unroll
-                for (int q = 1; q < NP; ++q) t = t + colred[tid + 128 * q];
-                dst[c] = t;
-            }
-            __syncthreads();
-        }
-    };
     // [dW_mu | dW_var] = h_L^T [dmu | dv] as one GEMM
     wg_gemm(U, 2 * O, Bt, (gcptr)hL, 1, U, (gcptr)dmu, U, 1,
-            GemmEpi{(gptr)(G + oWmu), O, nullptr, nullptr, 0, 0, (gptr)(G + oWv), nullptr, p.stamps}, GemmSplit{nullptr, (gcptr)dv, 0x7fffffff, O});
-    col_sums(dmu, O, G + obmu);
-    col_sums(dv, O, G + obv);
+            GemmEpi{(gptr)(G + oWmu), O, nullptr, nullptr, 0, 0, (gptr)(G + oWv), nullptr, p.stamps, (gptr)(G + obmu), (gptr)(G + obv)},
+            GemmSplit{nullptr, (gcptr)dv, 0x7fffffff, O});                    // + [db_mu | db_var] = column sums of [dmu | dv]
     // dh_L = (dmu Wmu^T + dv Wvar^T) * relu'(h_L): the relu mask rides in the epilogue of the GEMM that completes dh
     // dh_L = ([dmu | dv] [W_mu | W_var]^T) * relu'(h_L): one GEMM over K = 2O; the relu mask rides in its epilogue
     wg_gemm(Bt, U, 2 * O, (gcptr)dmu, U, 1, (gcptr)(W + oWmu), 1, O,
-            GemmEpi{(gptr)dha, U, nullptr, (gcptr)hL, U, 0, nullptr, nullptr, p.stamps}, GemmSplit{(gcptr)dv, (gcptr)(W + oWv), O, 0x7fffffff});
+            GemmEpi{(gptr)dha, U, nullptr, (gcptr)hL, U, 0, nullptr, nullptr, p.stamps, nullptr, nullptr}, GemmSplit{(gcptr)dv, (gcptr)(W + oWv), O, 0x7fffffff});
     CEM_TR_STAMP(6);
     float *dcur = dha, *dnext = dhb;
     for (int l = L - 1; l >= 0; --l) {
-        const float *hin = l == 0 ? xs : hs + (size_t)(l - 1) * CEM_TB * U;
+        const float *hin = l == 0 ? xs : hs + (size_t)(l - 1) * CEM_TROWS * U;
         const int in = l == 0 ? D : U;
-        wg_gemm(in, U, Bt, (gcptr)hin, 1, U, (gcptr)dcur, U, 1, GemmEpi{(gptr)(G + offW(l)), U, nullptr, nullptr, 0, 0, nullptr, nullptr, p.stamps}, CEM_NOSPLIT);        // dW_l = h_{l-1}^T dh_l
-        col_sums(dcur, U, G + offb(l));
+        wg_gemm(in, U, Bt, (gcptr)hin, 1, U, (gcptr)dcur, U, 1, GemmEpi{(gptr)(G + offW(l)), U, nullptr, nullptr, 0, 0, nullptr, nullptr, p.stamps, (gptr)(G + offb(l)), nullptr}, CEM_NOSPLIT);   // dW_l = h_{l-1}^T dh_l, db_l = column sums of dh_l
         if (l > 0) {
-            wg_gemm(Bt, U, U, (gcptr)dcur, U, 1, (gcptr)(W + offW(l)), 1, U, GemmEpi{(gptr)dnext, U, nullptr, (gcptr)hin, U, 0, nullptr, nullptr, p.stamps}, CEM_NOSPLIT);   // dh_{l-1} = (dh_l W_l^T) relu'
+            wg_gemm(Bt, U, U, (gcptr)dcur, U, 1, (gcptr)(W + offW(l)), 1, U, GemmEpi{(gptr)dnext, U, nullptr, (gcptr)hin, U, 0, nullptr, nullptr, p.stamps, nullptr, nullptr}, CEM_NOSPLIT);   // dh_{l-1} = (dh_l W_l^T) relu'
             float *t = dcur; dcur = dnext; dnext = t;
         }
     }
@@ -371,6 +512,7 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
 __global__ __launch_bounds__(256) void cem_adam_kernel(const TrainParams p)
 {
     const size_t n = (size_t)p.E * p.nat, n4 = n / 4;
+    const int nparts = (p.Bt + CEM_TROWS - 1) / CEM_TROWS;          // row parts that ran this step (a short last minibatch has fewer)
     const float ob1 = 1.0f - p.beta1, ob2 = 1.0f - p.beta2;
     auto upd = [&](float g, float &mo, float &vo, float &w) {
         g = fminf(fmaxf(g, -p.clip), p.clip);
@@ -381,13 +523,29 @@ __global__ __launch_bounds__(256) void cem_adam_kernel(const TrainParams p)
     float4 *W4 = reinterpret_cast<float4 *>(p.W), *M4 = reinterpret_cast<float4 *>(p.Mo), *V4 = reinterpret_cast<float4 *>(p.Vo);
     const float4 *G4 = reinterpret_cast<const float4 *>(p.grad);
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (size_t)gridDim.x * 256) {
-        const float4 g = G4[e];
+        float4 gp[CEM_TPARTS];
+#pragma unroll
+        for (int q = 0; q < CEM_TPARTS; ++q) gp[q] = G4[(q < nparts ? (size_t)q : 0) * n4 + e];      // all parts' loads in flight at once
+        float4 g = gp[0];                                            // dW = sum over the row parts, part 0 first: a fixed order
+#pragma unroll
+        for (int q = 1; q < CEM_TPARTS; ++q)
+            if (q < nparts) { g.x = g.x + gp[q].x; g.y = g.y + gp[q].y; g.z = g.z + gp[q].z; g.w = g.w + gp[q].w; }
         float4 mo = M4[e], vo = V4[e], w = W4[e];
         upd(g.x, mo.x, vo.x, w.x); upd(g.y, mo.y, vo.y, w.y); upd(g.z, mo.z, vo.z, w.z); upd(g.w, mo.w, vo.w, w.w);
         M4[e] = mo; V4[e] = vo; W4[e] = w;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t e = n4 * 4 + threadIdx.x;
-        upd(p.grad[e], p.Mo[e], p.Vo[e], p.W[e]);
+        float g = p.grad[e];
+        for (int q = 1; q < nparts; ++q) g = g + p.grad[(size_t)q * n + e];
+        upd(g, p.Mo[e], p.Vo[e], p.W[e]);
+    }
+    // training_step's return value, per member: negative_log_likelihood / ensemble_size (mlp_ensemble.py:64-67,139-141)
+    if (blockIdx.x == 0 && (int)threadIdx.x < p.E) {
+        const int m = threadIdx.x;
+        float s_log = 0.f, s_sq = 0.f;
+        for (int q = 0; q < nparts; ++q) { s_log = s_log + p.loss_part[((size_t)m * CEM_TPARTS + q) * 2]; s_sq = s_sq + p.loss_part[((size_t)m * CEM_TPARTS + q) * 2 + 1]; }
+        const float cnt = (float)p.Bt * (float)p.O;
+        p.loss_out[m] = (0.5f * s_log / cnt + 0.5f * s_sq / cnt) / (float)p.E;
     }
 }

@@ -112,16 +112,22 @@ class MlpEnsemble(object):
             perm_dev = torch.from_numpy(shuffles_per_mlp.astype(np.int32)).to(dev)
             perm_dev.record_stream(tr.stream)
             perms_alive.append(perm_dev)
-            for b in range(n_batches):
-                off, bt = int(bounds[b]), int(bounds[b + 1] - bounds[b])
-                tr.step(x_dev, y_dev, perm_dev, off, bt, self.learning_rate_at(tr.iterations), loss_dev[step])
-                step += 1
+            # the epoch's steps go down in runs of one library call each (cem_trainer_steps), cut where the reference logs a
+            # validation loss (:181-184) and at the end of training: no Python between the steps of a run
+            b = 0
+            while b < n_batches and step < self.training_steps:
+                until_log = log_every - step % log_every if xv_dev is not None else n_batches
+                run = min(n_batches - b, self.training_steps - step, until_log)
+                offs = bounds[b:b + run]
+                bts = bounds[b + 1:b + run + 1] - bounds[b:b + run]
+                lrs = [self.learning_rate_at(tr.iterations + i) for i in range(run)]
+                tr.steps(x_dev, y_dev, perm_dev, offs, bts, lrs, loss_dev[step:step + run])
+                step += run
+                b += run
                 if step % log_every == 0 and xv_dev is not None:                                              # :181-184
                     vl = tr.validation_loss(xv_dev, yv_dev)
                     logger.debug("Step {} | Training Loss {} | Validation Loss {}".format(
                         step, float(loss_dev[step - 1].sum().item()), vl))
-                if step == self.training_steps:
-                    break
         tr.synchronize()
         del perms_alive
         losses = loss_dev.sum(dim=1).cpu().numpy().astype(np.float64)

@@ -96,6 +96,20 @@ class CemTrainer:
                                               _ptr(loss_dev)), 'cem_trainer_step')
         self.iterations += 1
 
+    def steps(self, x_dev, y_dev, perm_dev, offsets, bts, lrs, loss_dev):
+        """len(offsets) consecutive training_steps in one library call (an epoch's inner loop): step s takes rows
+        perm[m, offsets[s]:offsets[s]+bts[s]] with learning rate lrs[s]; loss_dev is [n_steps, E]."""
+        n = len(offsets)
+        off = np.ascontiguousarray(np.asarray(offsets, np.int32))
+        bt = np.ascontiguousarray(np.asarray(bts, np.int32))
+        f = np.float32
+        t = self.iterations + 1 + np.arange(n)
+        lr_t = np.ascontiguousarray((np.asarray(lrs, f) * np.sqrt(1.0 - self.beta2 ** t).astype(f) / (1.0 - self.beta1 ** t).astype(f)).astype(f))
+        self.stream.wait_stream(self._torch.cuda.current_stream(self.device))
+        _capi.check(self.lib.cem_trainer_steps(self.h, _ptr(x_dev), _ptr(y_dev), _ptr(perm_dev), perm_dev.shape[1], n, _np_ptr(off),
+                                               _np_ptr(bt), _np_ptr(lr_t), _ptr(loss_dev)), 'cem_trainer_steps')
+        self.iterations += n
+
     def validation_loss(self, x_dev, y_dev):
         """MlpEnsemble.validation_step (mlp_ensemble.py:147-155)."""
         self.stream.wait_stream(self._torch.cuda.current_stream(self.device))

@@ -236,6 +236,11 @@ int cem_trainer_get_state(cem_trainer_t *h, float *weights, float *m, float *v);
  * loss_dev[ensemble_size] receives every member's share of the loss (their sum is training_step's return value) */
 int cem_trainer_step(cem_trainer_t *h, const float *x_dev, const float *y_dev, const int32_t *perm_dev, int32_t nperm,
                      int32_t offset, int32_t bt, float lr_t, float *loss_dev);
+/* n_steps consecutive training_steps in ONE call (an epoch of MlpEnsemble.fit's inner loop, mlp_ensemble.py:174-180): step s uses
+ * rows perm[member][offsets[s] .. offsets[s] + bts[s]) with step size lr_ts[s] (host arrays) and writes its members' losses to
+ * loss_dev[s * ensemble_size ..].  Same arithmetic as n_steps cem_trainer_step calls; the point is one host call per epoch. */
+int cem_trainer_steps(cem_trainer_t *h, const float *x_dev, const float *y_dev, const int32_t *perm_dev, int32_t nperm,
+                      int32_t n_steps, const int32_t *offsets, const int32_t *bts, const float *lr_ts, float *loss_dev);
 /* validation_step on rows [0, n) of x_dev / y_dev: *loss_out = sum over members of NLL / ensemble_size (synchronises) */
 int cem_trainer_eval(cem_trainer_t *h, const float *x_dev, const float *y_dev, int32_t n, float *loss_out);
 
