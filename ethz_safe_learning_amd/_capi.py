@@ -52,7 +52,7 @@ class CemConfig(C.Structure):
         ('act_mu0', C.c_float * CEM_MAX_ACT), ('act_sigma0', C.c_float * CEM_MAX_ACT),
         ('scorer', CemScorer),
         ('world_size', C.c_int32), ('rank', C.c_int32), ('chunks_per_tile', C.c_int32), ('use_graph', C.c_int32),
-        ('rollout_segments', C.c_int32),
+        ('select_mode', C.c_int32), ('rollout_segments', C.c_int32),
     ]
 
 

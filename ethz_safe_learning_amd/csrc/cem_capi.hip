@@ -59,6 +59,7 @@ int validate(const cem_config_t *c)
     if (c->variant != CEM_VARIANT_CEM && c->variant != CEM_VARIANT_SAFE) return CEM_ERR_INVALID_ARG;
     if (c->chunks_per_tile < 0 || c->chunks_per_tile > 4) return CEM_ERR_INVALID_ARG;
     if (c->rollout_segments < 0 || c->rollout_segments > 64) return CEM_ERR_INVALID_ARG;
+    if (c->select_mode < 0 || c->select_mode > 2) return CEM_ERR_INVALID_ARG;
     if ((long long)c->particles * c->n_samples > (1ll << 30)) return CEM_ERR_UNSUPPORTED;
     return CEM_OK;
 }
@@ -278,7 +279,8 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
     size_t ctrl, musig, scores_local, scores_global, actions, elite, returns, costs, result, wpack, bias_h, bias_mu, bias_var,
-        nmin, ndelta, omask, kind_sel, tiles, eps_out, stamps, seg_queue, seg_flags, seg_state, total;
+        nmin, ndelta, omask, kind_sel, tiles, eps_out, stamps, seg_queue, seg_flags, seg_state,
+        ms_hist, ms_sel, ms_counts, ms_best_sc, ms_best_ix, ms_part, ms_colmean, total;
 };
 
 struct Plan { int rc, n_tiles, n_seg, seg_len, n_pinned; };
@@ -328,6 +330,11 @@ Layout make_layout(const cem_config_t *c, const Dims &d, size_t max_tiles)
     const size_t n_float = (size_t)(pl.n_tiles - pl.n_pinned);
     l.seg_flags = take(std::max<size_t>(n_float * std::max(pl.n_seg - 1, 1), 1) * 4);
     l.seg_state = take(pl.n_seg > 1 ? std::max<size_t>(n_float, 1) * (2 * d.NFW * pl.rc * 256 + 64) * 16 : 16);
+    // multi-workgroup select (large populations): digit histograms, per-slice counts and best elites, moment partial sums
+    const size_t msG = ((size_t)d.N + CEM_MS_KEYS - 1) / CEM_MS_KEYS, msG2 = ((size_t)d.k + CEM_MS_EPG - 1) / CEM_MS_EPG;
+    l.ms_hist = take(3 * CEM_MS_BINS * 4); l.ms_sel = take(256);
+    l.ms_counts = take(msG * 2 * 4); l.ms_best_sc = take(msG * 4); l.ms_best_ix = take(msG * 4);
+    l.ms_part = take(2 * msG2 * (size_t)d.H * d.A * 4); l.ms_colmean = take((size_t)d.H * d.A * 4);
     l.total = o;
     return l;
 }
@@ -768,11 +775,31 @@ int enqueue_select(cem_planner *h, int it)
     size_t lds = (size_t)((d.k + 3) & ~3) * 4 + (size_t)2 * d.H * d.A * 4;
     const size_t dyn_limit = h->sel_dyn_limit;          // asked from the runtime at create(), per device
     const bool cache = lds + (size_t)d.N * 4 <= dyn_limit;
-    if (cache) lds += (size_t)d.N * 4;
+    // Populations whose keys do not fit the LDS of one workgroup go through the multi-workgroup chain (cem_mpc.h select_mode)
+    const bool multi = h->cfg.select_mode == 2 || (h->cfg.select_mode == 0 && !cache);
     size_t e0 = 0;
     if (h->timing) { e0 = h->ev_kind.size() * 2; h->ev_kind.push_back({(int)e0, 1}); hipEventRecord(get_event(h, e0), h->stream); }
-    if (cache) hipLaunchKernelGGL(cem_select_kernel<true>, dim3(1), dim3(1024), lds, h->stream, p);
-    else hipLaunchKernelGGL(cem_select_kernel<false>, dim3(1), dim3(1024), lds, h->stream, p);
+    if (multi) {
+        MSelParams m{}; m.scores = p.scores; m.actions = p.actions; m.musig = p.musig; m.ctrl = p.ctrl; m.elite_idx = p.elite_idx;
+        m.hist = (uint32_t *)(ws + l.ms_hist); m.sel = (uint32_t *)(ws + l.ms_sel); m.wg_counts = (uint32_t *)(ws + l.ms_counts);
+        m.best_sc = (float *)(ws + l.ms_best_sc); m.best_ix = (int32_t *)(ws + l.ms_best_ix);
+        m.part = (float *)(ws + l.ms_part); m.colmean = (float *)(ws + l.ms_colmean);
+        m.N = d.N; m.k = d.k; m.HA = p.HA; m.A = d.A; m.check_done = 1; m.smoothing = p.smoothing; m.threshold = p.threshold;
+        m.G = (d.N + CEM_MS_KEYS - 1) / CEM_MS_KEYS; m.G2 = (d.k + CEM_MS_EPG - 1) / CEM_MS_EPG;
+        HIPCHK(hipMemsetAsync(m.hist, 0, 3 * CEM_MS_BINS * 4, h->stream));
+        hipLaunchKernelGGL(cem_msel_hist_kernel<0>, dim3(m.G), dim3(1024), 0, h->stream, m);
+        hipLaunchKernelGGL(cem_msel_hist_kernel<1>, dim3(m.G), dim3(1024), 0, h->stream, m);
+        hipLaunchKernelGGL(cem_msel_hist_kernel<2>, dim3(m.G), dim3(1024), 0, h->stream, m);
+        hipLaunchKernelGGL(cem_msel_count_kernel, dim3(m.G), dim3(1024), 0, h->stream, m);
+        hipLaunchKernelGGL(cem_msel_compact_kernel, dim3(m.G), dim3(1024), 0, h->stream, m);
+        hipLaunchKernelGGL(cem_msel_moments_kernel<0>, dim3(m.G2), dim3(256), 0, h->stream, m);
+        hipLaunchKernelGGL(cem_msel_moments_kernel<1>, dim3(m.G2), dim3(256), 0, h->stream, m);
+        hipLaunchKernelGGL(cem_msel_final_kernel, dim3(1), dim3(256), 0, h->stream, m);
+    } else {
+        if (cache) lds += (size_t)d.N * 4;
+        if (cache) hipLaunchKernelGGL(cem_select_kernel<true>, dim3(1), dim3(1024), lds, h->stream, p);
+        else hipLaunchKernelGGL(cem_select_kernel<false>, dim3(1), dim3(1024), lds, h->stream, p);
+    }
     HIPCHK(hipGetLastError());
     if (h->timing) hipEventRecord(get_event(h, e0 + 1), h->stream);
     return CEM_OK;

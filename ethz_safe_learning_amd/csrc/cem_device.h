@@ -1248,6 +1248,242 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same selection for LARGE populations (the replicated select of a many-GPU plan: B5 has N = 65536, k = 6554) as a chain
+// of multi-workgroup kernels.  One workgroup cannot hold 65536 keys in LDS; its global-memory radix passes took 190 us of a
+// 280-us kernel (scripts/stamp_select.py).  Here: three histogram kernels (11 + 11 + 10 bit digits of the order-preserving key,
+// per-workgroup LDS histograms flushed with integer atomics — exact and order-independent), a count and a compaction kernel
+// (elite indices in ascending candidate order, ties lowest index first, as tf.nn.top_k), two moment kernels (partial sums
+// over groups of 256 elites, combined in group order: deterministic) and a one-workgroup tail (smoothing, early stop,
+// best-so-far).  Every workgroup recomputes the few scalars it needs (digit of the k-th key, ...) from the global
+// histograms instead of waiting for another workgroup.
+// ---------------------------------------------------------------------------------------------------------
+#define CEM_MS_KEYS 4096              // keys per workgroup (1024 threads x 4) in the histogram / count / compaction kernels
+#define CEM_MS_BINS 2048
+#define CEM_MS_EPG 256                // elites per workgroup in the moment kernels
+struct MSelParams {
+    const float *scores; const float *actions; float *musig; CtrlBlock *ctrl; int32_t *elite_idx;
+    uint32_t *hist;                   // [3][CEM_MS_BINS] digit histograms (zeroed before the first pass)
+    uint32_t *sel;                    // [2] key of the k-th largest score, ties to take
+    uint32_t *wg_counts;              // [G][2] keys > T / == T in each workgroup's slice
+    float *best_sc; int32_t *best_ix; // [G] best elite of each slice (score, candidate)
+    float *part;                      // [2][G2][HA] partial sums of the two moment passes
+    float *colmean;                   // [HA] elite mean, later the smoothed sigma
+    int32_t N, k, HA, A, check_done, G, G2;
+    float smoothing, threshold;
+};
+
+// block-wide (1024 threads): the bin b with ge[b] >= need > ge[b + 1], ge[b] = #keys in bins >= b; returns (b, need - ge[b + 1])
+__device__ __forceinline__ void cem_ms_find(const uint32_t *h, const int nbins, const uint32_t need, uint32_t *sh /* [20] */, uint32_t &bin, uint32_t &need_next)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b0 = 2 * tid, b1 = 2 * tid + 1;
+    const uint32_t h0 = b0 < nbins ? h[b0] : 0u, h1 = b1 < nbins ? h[b1] : 0u;
+    const uint32_t tot = h0 + h1;
+    uint32_t inc = tot;                                   // inclusive prefix over lower thread ids
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+    if (lane == 63) sh[wv] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (int i = 0; i < 16; ++i) { const uint32_t v = sh[i]; all += v; if (i < wv) before += v; }
+    const uint32_t above = all - (before + inc);          // keys in bins of higher thread ids
+    const uint32_t ge1 = h1 + above, ge0 = tot + above;
+    if (ge1 >= need && above < need) { sh[16] = (uint32_t)b1; sh[17] = need - above; }
+    if (ge0 >= need && ge1 < need) { sh[16] = (uint32_t)b0; sh[17] = need - ge1; }
+    __syncthreads();
+    bin = sh[16]; need_next = sh[17];
+    __syncthreads();
+}
+
+template <int PASS>
+__global__ __launch_bounds__(1024) void cem_msel_hist_kernel(const MSelParams p)
+{
+    __shared__ uint32_t lh[CEM_MS_BINS];
+    __shared__ uint32_t sh[20];
+    if (p.check_done && p.ctrl->done) return;
+    const int tid = threadIdx.x;
+    uint32_t need = (uint32_t)p.k, b0 = 0, b1 = 0;
+    if (PASS >= 1) cem_ms_find(p.hist, CEM_MS_BINS, need, sh, b0, need);
+    if (PASS >= 2) cem_ms_find(p.hist + CEM_MS_BINS, CEM_MS_BINS, need, sh, b1, need);
+    for (int b = tid; b < CEM_MS_BINS; b += 1024) lh[b] = 0u;
+    __syncthreads();
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int i = blockIdx.x * CEM_MS_KEYS + j * 1024 + tid; v[j] = i < p.N ? p.scores[i] : 0.f; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = blockIdx.x * CEM_MS_KEYS + j * 1024 + tid;
+        if (i < p.N) {
+            const uint32_t key = cem_f2key(v[j]);
+            if (PASS == 0) atomicAdd(&lh[key >> 21], 1u);
+            else if (PASS == 1) { if ((key >> 21) == b0) atomicAdd(&lh[(key >> 10) & 2047u], 1u); }
+            else { if ((key >> 10) == ((b0 << 11) | b1)) atomicAdd(&lh[key & 1023u], 1u); }
+        }
+    }
+    __syncthreads();
+    for (int b = tid; b < CEM_MS_BINS; b += 1024) { const uint32_t c = lh[b]; if (c) atomicAdd(&p.hist[PASS * CEM_MS_BINS + b], c); }
+}
+
+__global__ __launch_bounds__(1024) void cem_msel_count_kernel(const MSelParams p)
+{
+    __shared__ uint32_t sh[20];
+    __shared__ uint32_t red[2][16];
+    if (p.check_done && p.ctrl->done) return;
+    const int tid = threadIdx.x;
+    uint32_t need = (uint32_t)p.k, b0, b1, b2;
+    cem_ms_find(p.hist, CEM_MS_BINS, need, sh, b0, need);
+    cem_ms_find(p.hist + CEM_MS_BINS, CEM_MS_BINS, need, sh, b1, need);
+    cem_ms_find(p.hist + 2 * CEM_MS_BINS, 1024, need, sh, b2, need);
+    const uint32_t T = (b0 << 21) | (b1 << 10) | b2;
+    if (blockIdx.x == 0 && tid == 0) { p.sel[0] = T; p.sel[1] = need; }
+    uint32_t ngt = 0, neq = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = blockIdx.x * CEM_MS_KEYS + 4 * tid + j;              // the same key -> thread map as the compaction kernel
+        if (i < p.N) { const uint32_t key = cem_f2key(p.scores[i]); ngt += key > T; neq += key == T; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { ngt += __shfl_xor(ngt, d); neq += __shfl_xor(neq, d); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = ngt; red[1][tid >> 6] = neq; }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t a = 0, b = 0;
+        for (int i = 0; i < 16; ++i) { a += red[0][i]; b += red[1][i]; }
+        p.wg_counts[2 * blockIdx.x] = a; p.wg_counts[2 * blockIdx.x + 1] = b;
+    }
+}
+
+__global__ __launch_bounds__(1024) void cem_msel_compact_kernel(const MSelParams p)
+{
+    __shared__ uint32_t wsum[2][16];
+    __shared__ uint32_t base[2];
+    __shared__ float bsc[16];
+    __shared__ int bix[16];
+    if (p.check_done && p.ctrl->done) return;
+    const int tid = threadIdx.x;
+    const uint32_t T = p.sel[0], need = p.sel[1];
+    // keys > T / == T in the slices before this one (ascending candidate order = ascending workgroup order)
+    {
+        uint32_t a = 0, b = 0;
+        for (int g = tid; g < (int)blockIdx.x; g += 1024) { a += p.wg_counts[2 * g]; b += p.wg_counts[2 * g + 1]; }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
+        if ((tid & 63) == 0) { wsum[0][tid >> 6] = a; wsum[1][tid >> 6] = b; }
+        __syncthreads();
+        if (tid == 0) { uint32_t x = 0, y = 0; for (int i = 0; i < 16; ++i) { x += wsum[0][i]; y += wsum[1][i]; } base[0] = x; base[1] = y; }
+        __syncthreads();
+    }
+    const uint32_t gt_before = base[0], eq_before = base[1];
+    __syncthreads();
+    uint32_t key[4]; float sc[4];
+    uint32_t ngt = 0, neq = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = blockIdx.x * CEM_MS_KEYS + 4 * tid + j;
+        sc[j] = i < p.N ? p.scores[i] : 0.f;
+        key[j] = i < p.N ? cem_f2key(sc[j]) : 0u;
+        if (i < p.N) { ngt += key[j] > T; neq += key[j] == T; }
+    }
+    uint32_t pre_gt, pre_eq;
+    cem_block_excl_scan2(ngt, neq, wsum, pre_gt, pre_eq);
+    uint32_t eqr = eq_before + pre_eq;
+    uint32_t pos = gt_before + pre_gt + (eqr < need ? eqr : need);
+    float bs = -__builtin_inff(); int bi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = blockIdx.x * CEM_MS_KEYS + 4 * tid + j;
+        if (i < p.N) {
+            bool take = key[j] > T;
+            if (key[j] == T) { take = eqr < need; ++eqr; }
+            if (take) {
+                p.elite_idx[pos++] = i;
+                if (bi == 0x7fffffff || sc[j] > bs) { bs = sc[j]; bi = i; }      // ascending i: the first maximum is the lowest index
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float os = __shfl_xor(bs, d); const int oi = __shfl_xor(bi, d);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; }
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { bsc[tid >> 6] = bs; bix[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < 16; ++i) { const float os = bsc[i]; const int oi = bix[i]; if (oi != 0x7fffffff && (bi == 0x7fffffff || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; } }
+        p.best_sc[blockIdx.x] = bs; p.best_ix[blockIdx.x] = bi;
+    }
+}
+
+// moments over the elite set (tf.nn.moments: mean, then mean squared difference).  Workgroup g owns elites [256 g, 256 g + 256);
+// thread (sub, col) adds the values of column col over every fourth... over the elites e = sub, sub + 4, ... of its group, the four
+// sub-sums are added in order, the groups' partial sums are added in group order by whoever needs the total: a fixed order.
+template <int PHASE>
+__global__ __launch_bounds__(256) void cem_msel_moments_kernel(const MSelParams p)
+{
+    __shared__ float red[4][64];
+    if (p.check_done && p.ctrl->done) return;
+    const int tid = threadIdx.x, sub = tid >> 6, lc = tid & 63;
+    const int e0 = blockIdx.x * CEM_MS_EPG, e1 = (e0 + CEM_MS_EPG < p.k) ? e0 + CEM_MS_EPG : p.k;
+    const float fk = (float)p.k;
+    for (int c0 = 0; c0 < p.HA; c0 += 64) {
+        const int col = c0 + lc;
+        const bool live = col < p.HA;
+        float mean = 0.f;
+        if (PHASE == 1 && live) {
+            float t = 0.f;
+            for (int g = 0; g < p.G2; ++g) t = t + p.part[(size_t)g * p.HA + col];
+            mean = t / fk;
+            if (blockIdx.x == 0 && sub == 0) p.colmean[col] = mean;
+        }
+        float acc = 0.f;
+        if (live) {
+            for (int e = e0 + sub; e < e1; e += 32) {                      // 8 gathers in flight
+                float a[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int ee = e + 4 * j; a[j] = ee < e1 ? p.actions[(size_t)p.elite_idx[ee] * p.HA + col] : 0.f; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (e + 4 * j < e1) acc = PHASE ? acc + (a[j] - mean) * (a[j] - mean) : acc + a[j];
+            }
+        }
+        red[sub][lc] = acc;
+        __syncthreads();
+        if (sub == 0 && live) p.part[((size_t)PHASE * p.G2 + blockIdx.x) * p.HA + col] = ((red[0][lc] + red[1][lc]) + red[2][lc]) + red[3][lc];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void cem_msel_final_kernel(const MSelParams p)
+{
+    if (p.check_done && p.ctrl->done) return;
+    const int tid = threadIdx.x;
+    const float fk = (float)p.k, sm = p.smoothing;
+    for (int col = tid; col < p.HA; col += 256) {
+        float t = 0.f;
+        for (int g = 0; g < p.G2; ++g) t = t + p.part[((size_t)p.G2 + g) * p.HA + col];
+        const float sd = sqrtf(t / fk);
+        const float nsg = sm * p.musig[p.HA + col] + (1.0f - sm) * sd;                   // cem_mpc.py:65
+        p.musig[col] = sm * p.musig[col] + (1.0f - sm) * p.colmean[col];                 // cem_mpc.py:64
+        p.musig[p.HA + col] = nsg;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float ssum = 0.f;
+        for (int i = 0; i < p.HA; ++i) ssum = ssum + p.musig[p.HA + i];
+        p.ctrl->iters = p.ctrl->iters + 1;
+        if (ssum / (float)p.HA <= p.threshold) p.ctrl->done = 1;                         // cem_mpc.py:66-67
+    }
+    if (tid == 64) {
+        float bs = p.best_sc[0]; int bi = p.best_ix[0];
+        for (int g = 1; g < p.G; ++g) { const float os = p.best_sc[g]; const int oi = p.best_ix[g]; if (oi != 0x7fffffff && (bi == 0x7fffffff || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; } }
+        if (bi != 0x7fffffff && bs > p.ctrl->best_score) {                                // strict (cem_mpc.py:58)
+            for (int a = 0; a < p.A; ++a) p.ctrl->best[a] = p.actions[(size_t)bi * p.HA + a];
+            p.ctrl->best_score = bs;
+        }
+    }
+}
+
 struct FinalParams { const CtrlBlock *ctrl; const float *eps_out; float *result; int32_t A; float noise_stddev; };
 
 __global__ void cem_final_kernel(const FinalParams p)

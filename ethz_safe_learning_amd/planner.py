@@ -60,6 +60,7 @@ class PlannerConfig:
     chunks_per_tile: int = 0
     use_graph: bool = False
     rollout_segments: int = 0          # 0 auto, 1 off, n > 1: horizon-segment work queue (cem_mpc.h)
+    select_mode: int = 0               # 0 auto, 1 one-workgroup select, 2 multi-workgroup select chain (cem_mpc.h)
 
 
 def sampling_params(low, high):
@@ -109,6 +110,7 @@ def to_c_config(cfg: PlannerConfig) -> _capi.CemConfig:
         c.scorer.cost_lo[i], c.scorer.cost_hi[i], c.scorer.cost_size[i] = int(lo), int(hi), float(size)
     c.world_size, c.rank, c.chunks_per_tile, c.use_graph = cfg.world_size, cfg.rank, cfg.chunks_per_tile, int(cfg.use_graph)
     c.rollout_segments = int(cfg.rollout_segments)
+    c.select_mode = int(cfg.select_mode)
     return c
 
 
