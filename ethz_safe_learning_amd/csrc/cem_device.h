@@ -1417,8 +1417,8 @@ __global__ __launch_bounds__(1024) void cem_msel_compact_kernel(const MSelParams
 }
 
 // moments over the elite set (tf.nn.moments: mean, then mean squared difference).  Workgroup g owns elites [256 g, 256 g + 256);
-// thread (sub, col) adds the values of column col over every fourth... over the elites e = sub, sub + 4, ... of its group, the four
-// sub-sums are added in order, the groups' partial sums are added in group order by whoever needs the total: a fixed order.
+// thread (sub, col) adds column col over the elites e = sub, sub + 4, ... of its group, the four sub-sums are added in order
+// 0..3, and the groups' partial sums are added in group order by whoever needs the total: a fixed order.
 template <int PHASE>
 __global__ __launch_bounds__(256) void cem_msel_moments_kernel(const MSelParams p)
 {
