@@ -282,22 +282,20 @@ __device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], f
 // Segment state crosses CUs — and XCDs, whose L2s are not coherent with each other for ordinary accesses.  An agent-scope
 // acquire / release FENCE would make them so by invalidating / writing back the whole L2 (buffer_inv sc1 / buffer_wbl2 sc1),
 // i.e. by evicting the ensemble weights every other workgroup of the XCD is streaming from it — measured 2.8x slower.  So the
-// few KB of state move with agent-scope RELAXED ATOMIC loads and stores (sc1 accesses: performed at the device coherence
-// point, no cache maintenance), the flag likewise, and the order "state, then flag" is kept by waiting for the stores'
-// acknowledgements (s_waitcnt vmcnt(0)) before the flag is written.
-__device__ __forceinline__ f4 cem_ld_coherent(const f4 *p)
+// few KB of state move with sc1 loads and stores (performed at the device coherence point, no cache maintenance — what an
+// agent-scope relaxed atomic access is on gfx940+), the flag likewise, and the order "state, then flag" is kept by waiting for
+// the stores' acknowledgements (s_waitcnt vmcnt(0)) before the flag is written.
+// ... as 16-byte buffer accesses with the sc1 cache-policy bit (aux bit 4 on gfx940+), the same instruction form the compiler
+// emits for agent-scope relaxed atomics, four words at a time.
+typedef unsigned int cem_u4 __attribute__((ext_vector_type(4)));
+#define CEM_AUX_SC1 16
+__device__ __forceinline__ f4 cem_ld_coherent(__amdgpu_buffer_rsrc_t rsrc, int byte_off)
 {
-    const float *q = reinterpret_cast<const float *>(p);
-    f4 v;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = __hip_atomic_load(q + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return v;
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, CEM_AUX_SC1));
 }
-__device__ __forceinline__ void cem_st_coherent(f4 *p, const f4 v)
+__device__ __forceinline__ void cem_st_coherent(__amdgpu_buffer_rsrc_t rsrc, int byte_off, const f4 v)
 {
-    float *q = reinterpret_cast<float *>(p);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) __hip_atomic_store(q + r, v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cem_u4, v), rsrc, byte_off, 0, CEM_AUX_SC1);
 }
 
 // One tile for steps [t_begin, t_end) of the horizon.  SEG false: the whole horizon (t_begin = 0, t_end = H).  SEG true: one
@@ -313,7 +311,10 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
     const int j = lane & 15, q = lane >> 4;
     const TileDesc td = p.tiles[tile_idx];
     const bool resumed = SEG && t_begin > 0;
-    f4 *const seg_st = SEG ? p.seg_state + (size_t)(tile_idx - p.n_pinned) * (2 * NFW * RC * 256 + 64) : nullptr;
+    // this tile's slot of the hand-over buffer as a buffer resource: [2*NFW*RC][256 threads] f4 + [64 lanes] f4
+    const __amdgpu_buffer_rsrc_t seg_rs = __builtin_amdgcn_make_buffer_rsrc(
+        SEG ? const_cast<f4 *>(p.seg_state + (size_t)(tile_idx - p.n_pinned) * (2 * NFW * RC * 256 + 64)) : const_cast<f4 *>(p.wpack), 0,
+        (2 * NFW * RC * 256 + 64) * 16, 0x00020000);
     const int O = p.O, A = p.A, H = p.H;
     constexpr int XB = RC * CEM_NG * 1024;
     float *part = reinterpret_cast<float *>(smem + 2 * XB);
@@ -341,7 +342,7 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
         const int f0 = 16 * (w + 4 * i) + 4 * q;
 #pragma unroll
         for (int c = 0; c < RC; ++c) {
-            if (resumed) { s[i][c] = cem_ld_coherent(seg_st + (i * RC + c) * 256 + tid); continue; }
+            if (resumed) { s[i][c] = cem_ld_coherent(seg_rs, ((i * RC + c) * 256 + tid) * 16); continue; }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int f = f0 + r;
@@ -397,13 +398,13 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
         for (int i = 0; i < NFW; ++i)
 #pragma unroll
             for (int c = 0; c < RC; ++c) {
-                const f4 x = cem_ld_coherent(seg_st + ((NFW + i) * RC + c) * 256 + tid);
+                const f4 x = cem_ld_coherent(seg_rs, (((NFW + i) * RC + c) * 256 + tid) * 16);
                 hB[i][c] = x;
                 *reinterpret_cast<f4 *>(smem + ((c * CEM_NG + w + 4 * i) * 64 + lane) * 16) = x;
             }
         xw = XB;
         if (w == 0) {
-            const f4 b = cem_ld_coherent(seg_st + 2 * NFW * RC * 256 + lane);
+            const f4 b = cem_ld_coherent(seg_rs, (2 * NFW * RC * 256 + lane) * 16);
             d_prev = b[0]; c_prev = b[1]; cum = b[2]; done = b[3] != 0.f;
         }
     }
@@ -616,10 +617,10 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
         for (int i = 0; i < NFW; ++i)
 #pragma unroll
             for (int c = 0; c < RC; ++c) {
-                cem_st_coherent(seg_st + (i * RC + c) * 256 + tid, s[i][c]);
-                cem_st_coherent(seg_st + ((NFW + i) * RC + c) * 256 + tid, hB[i][c]);
+                cem_st_coherent(seg_rs, ((i * RC + c) * 256 + tid) * 16, s[i][c]);
+                cem_st_coherent(seg_rs, (((NFW + i) * RC + c) * 256 + tid) * 16, hB[i][c]);
             }
-        if (w == 0) cem_st_coherent(seg_st + 2 * NFW * RC * 256 + lane, (f4){d_prev, c_prev, cum, done ? 1.0f : 0.0f});
+        if (w == 0) cem_st_coherent(seg_rs, (2 * NFW * RC * 256 + lane) * 16, (f4){d_prev, c_prev, cum, done ? 1.0f : 0.0f});
     }
 #ifdef CEM_STAMPS
     if (p.stamps && lane == 0) for (int i = 0; i < 8; ++i) p.stamps[((size_t)tile_idx * 4 + w) * 8 + i] = st_[i];

@@ -27,8 +27,8 @@ with open(os.path.join(out, 'summary_pmc.csv'), 'w') as fh:
     fh.write('kernel,counter,dispatches,mean_per_dispatch,pass\n')
     for r in rows:
         fh.write('"%s",%s,%d,%g,%s\n' % r)
-roll = {c: m for k, c, n, m, p in rows if 'cem_rollout_kernel' in k}
-kern = next((k for k, c, n, m, p in rows if 'cem_rollout_kernel' in k), None)
+roll = {c: m for k, c, n, m, p in rows if 'cem_rollout_' in k}
+kern = next((k for k, c, n, m, p in rows if 'cem_rollout_' in k), None)
 if roll:
     hit, miss = roll.get('TCC_HIT_sum', 0.0), roll.get('TCC_MISS_sum', 0.0)
     t = {'kernel': kern, 'workload': 'B2', 'fetch_size_kb': roll.get('FETCH_SIZE'), 'write_size_kb': roll.get('WRITE_SIZE'),
