@@ -36,7 +36,8 @@ int validate(const cem_config_t *c)
         c->particles < 1 || c->n_samples < 1 || c->horizon < 1 || c->horizon > 65535 || c->iterations < 1 || c->iterations > 65535 ||
         c->n_elite < 1 || c->n_elite > c->n_samples || c->world_size < 1 || c->rank < 0 || c->rank >= c->world_size)
         return CEM_ERR_INVALID_ARG;
-    if (c->units != CEM_U) return CEM_ERR_UNSUPPORTED;
+    if (c->units < 1) return CEM_ERR_INVALID_ARG;
+    if (c->units > CEM_U) return CEM_ERR_UNSUPPORTED;     // narrower layers run zero-padded to 128 (exactly: the padding adds zeros)
     if (c->obs_dim + c->act_dim > CEM_U) return CEM_ERR_UNSUPPORTED;
     if (c->n_samples % c->world_size != 0) return CEM_ERR_INVALID_ARG;
     if (((long long)c->particles * c->n_samples) % c->ensemble_size != 0) return CEM_ERR_SPLIT;
@@ -419,7 +420,7 @@ const char *cem_status_string(int s)
     switch (s) {
     case CEM_OK: return "ok";
     case CEM_ERR_INVALID_ARG: return "invalid argument";
-    case CEM_ERR_UNSUPPORTED: return "unsupported configuration (units must be 128, obs+act <= 128, task 'goal')";
+    case CEM_ERR_UNSUPPORTED: return "unsupported configuration (units <= 128, obs+act <= 128, task 'goal')";
     case CEM_ERR_SPLIT: return "particles*n_samples is not divisible by ensemble_size (tf.split would raise)";
     case CEM_ERR_WORKSPACE: return "workspace too small or misaligned";
     case CEM_ERR_HIP: return "HIP runtime error (see cem_last_hip_error)";
@@ -1155,7 +1156,8 @@ int validate_train(const cem_train_config_t *c)
 {
     if (!c || c->abi_version != CEM_ABI_VERSION) return CEM_ERR_INVALID_ARG;
     if (c->inputs_dim < 1 || c->outputs_dim < 1 || c->n_layers < 1 || c->ensemble_size < 1 || c->batch_size < 1) return CEM_ERR_INVALID_ARG;
-    if (c->units != CEM_U || c->inputs_dim > CEM_U || c->outputs_dim > CEM_U || c->batch_size > CEM_TB) return CEM_ERR_UNSUPPORTED;
+    if (c->units < 1) return CEM_ERR_INVALID_ARG;
+    if (c->units > CEM_U || c->inputs_dim > CEM_U || c->outputs_dim > CEM_U || c->batch_size > CEM_TB) return CEM_ERR_UNSUPPORTED;
     return CEM_OK;
 }
 size_t train_nat(const cem_train_config_t *c)
@@ -1167,7 +1169,7 @@ void train_layout(cem_trainer *t)
 {
     const cem_train_config_t &c = t->cfg;
     t->nat = train_nat(&c);
-    t->scratch_pm = (size_t)(c.n_layers + 8) * CEM_TROWS * c.units;      // per (member, row part) workgroup
+    t->scratch_pm = (size_t)(c.n_layers + 8) * CEM_TROWS * CEM_TS;       // per (member, row part) workgroup
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
     t->oW = take(t->nat * c.ensemble_size * 4); t->oM = take(t->nat * c.ensemble_size * 4); t->oV = take(t->nat * c.ensemble_size * 4);

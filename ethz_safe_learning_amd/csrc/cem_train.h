@@ -16,6 +16,7 @@
 
 #define CEM_TB 64            // max minibatch rows per member (config/models.yaml:4 batch_size: 64)
 #define CEM_TROWS 16         // minibatch rows per workgroup
+#define CEM_TS 128           // row stride of every activation matrix in the scratch (inputs_dim, outputs_dim, units <= 128)
 #define CEM_TPARTS (CEM_TB / CEM_TROWS)
 
 struct TrainParams {
@@ -413,16 +414,17 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
     if (Bt <= 0) return;                          // a short minibatch: the Adam kernel only adds the parts that exist
     float *W = p.W + (size_t)m * p.nat, *G = p.grad + ((size_t)part * p.E + m) * p.nat;
     float *sc = p.scratch + (size_t)blockIdx.x * p.scratch_per_member;
-    // scratch carve (row stride U for every activation matrix; D, O <= U)
-    float *xs = sc;                              // [TROWS][U]   h_0
-    float *hs = xs + CEM_TROWS * U;              // [L][TROWS][U] h_1..h_L
-    float *mu = hs + (size_t)L * CEM_TROWS * U;  // [TROWS][U]
-    float *vp = mu + CEM_TROWS * U;
-    float *ys = vp + CEM_TROWS * U;
-    float *dmu = ys + CEM_TROWS * U;
-    float *dv = dmu + CEM_TROWS * U;
-    float *dha = dv + CEM_TROWS * U;
-    float *dhb = dha + CEM_TROWS * U;
+    // scratch carve: every activation matrix has row stride S = CEM_TS (D, O, U <= 128; units below 128 leave columns unused)
+    constexpr int S = CEM_TS;
+    float *xs = sc;                              // [TROWS][S]   h_0
+    float *hs = xs + CEM_TROWS * S;              // [L][TROWS][S] h_1..h_L
+    float *mu = hs + (size_t)L * CEM_TROWS * S;  // [TROWS][S]
+    float *vp = mu + CEM_TROWS * S;
+    float *ys = vp + CEM_TROWS * S;
+    float *dmu = ys + CEM_TROWS * S;
+    float *dv = dmu + CEM_TROWS * S;
+    float *dha = dv + CEM_TROWS * S;
+    float *dhb = dha + CEM_TROWS * S;
     // natural-blob offsets (cem_mpc.h): W_0,b_0,...,W_mu,b_mu,W_var,b_var
     auto offW = [&](int l) { return l == 0 ? (size_t)0 : (size_t)D * U + U + (size_t)(l - 1) * ((size_t)U * U + U); };
     auto offb = [&](int l) { return offW(l) + (size_t)(l == 0 ? D : U) * U; };
@@ -438,8 +440,8 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
         int32_t *rows = reinterpret_cast<int32_t *>(lds);
         if (tid < Bt) rows[tid] = p.perm ? p.perm[(size_t)m * p.nperm + p.offset + row0 + tid] : p.offset + row0 + tid;
         __syncthreads();
-        wg_map<float2>(Bt * U,
-            [&](int e) { const int r = e / U, c = e % U; const int row = rows[r];
+        wg_map<float2>(Bt * S,
+            [&](int e) { const int r = e / S, c = e % S; const int row = rows[r];
                          return make_float2(c < D ? p.x[(size_t)row * D + c] : 0.f, c < O ? p.y[(size_t)row * O + c] : 0.f); },
             [&](int e, float2 v) { xs[e] = v.x; ys[e] = v.y; });
     }
@@ -448,22 +450,22 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
     CEM_TR_STAMP(1);
     // ---- forward (mlp_ensemble.py:18-22,33-34,59-61) -----------------------------------------------------------
     for (int l = 0; l < L; ++l) {
-        const float *hin = l == 0 ? xs : hs + (size_t)(l - 1) * CEM_TROWS * U;
-        float *hout = hs + (size_t)l * CEM_TROWS * U;
+        const float *hin = l == 0 ? xs : hs + (size_t)(l - 1) * CEM_TROWS * S;
+        float *hout = hs + (size_t)l * CEM_TROWS * S;
         const float *Wl = W + offW(l), *bl = W + offb(l);
-        wg_gemm(Bt, U, l == 0 ? D : U, (gcptr)hin, U, 1, (gcptr)Wl, U, 1, GemmEpi{(gptr)hout, U, (gcptr)bl, nullptr, 0, 1, nullptr, nullptr, p.stamps, nullptr, nullptr}, CEM_NOSPLIT);     // relu(h W + b)
+        wg_gemm(Bt, U, l == 0 ? D : U, (gcptr)hin, S, 1, (gcptr)Wl, U, 1, GemmEpi{(gptr)hout, S, (gcptr)bl, nullptr, 0, 1, nullptr, nullptr, p.stamps, nullptr, nullptr}, CEM_NOSPLIT);     // relu(h W + b)
     }
     CEM_TR_STAMP(2);
-    const float *hL = hs + (size_t)(L - 1) * CEM_TROWS * U;
+    const float *hL = hs + (size_t)(L - 1) * CEM_TROWS * S;
     // both heads as ONE GEMM: columns [0, O) = mu head, [O, 2O) = variance head (2O <= 128 fills the tile two N = O GEMMs half use)
-    wg_gemm(Bt, 2 * O, U, (gcptr)hL, U, 1, (gcptr)(W + oWmu), O, 1,
-            GemmEpi{(gptr)mu, U, (gcptr)(W + obmu), nullptr, 0, 0, (gptr)vp, (gcptr)(W + obv), p.stamps, nullptr, nullptr}, GemmSplit{nullptr, (gcptr)(W + oWv), 0x7fffffff, O});
+    wg_gemm(Bt, 2 * O, U, (gcptr)hL, S, 1, (gcptr)(W + oWmu), O, 1,
+            GemmEpi{(gptr)mu, S, (gcptr)(W + obmu), nullptr, 0, 0, (gptr)vp, (gcptr)(W + obv), p.stamps, nullptr, nullptr}, GemmSplit{nullptr, (gcptr)(W + oWv), 0x7fffffff, O});
     CEM_TR_STAMP(3);
     // ---- negative_log_likelihood (:64-67) and its gradient w.r.t. mu and the pre-softplus variance -----------------
     float s_log = 0.f, s_sq = 0.f;
     const float ninv = 1.0f / ((float)p.Bt * (float)O * (float)p.E);          // the mean runs over the WHOLE minibatch (mlp_ensemble.py:64-67)
     wg_map<float3>(Bt * O,
-        [&](int e) { const int r = e / O, c = e % O; return make_float3(vp[r * U + c], mu[r * U + c], ys[r * U + c]); },
+        [&](int e) { const int r = e / O, c = e % O; return make_float3(vp[r * S + c], mu[r * S + c], ys[r * S + c]); },
         [&](int e, float3 in) {
             const int r = e / O, c = e % O;
             const float v = in.x, var = train_softplus(v) + 1e-4f;
@@ -471,9 +473,9 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
             s_log += logf(6.283185307179586f * var);
             s_sq += diff * diff / var;
             if (p.train) {
-                dmu[r * U + c] = diff / var * ninv;
+                dmu[r * S + c] = diff / var * ninv;
                 const float dvar = (0.5f / var - 0.5f * diff * diff / (var * var)) * ninv;
-                dv[r * U + c] = dvar / (1.0f + expf(-v));               // d softplus(v)/dv = sigmoid(v)
+                dv[r * S + c] = dvar / (1.0f + expf(-v));               // d softplus(v)/dv = sigmoid(v)
             }
         });
     s_log = block_sum(s_log, red);
@@ -487,21 +489,21 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
     CEM_TR_STAMP(5);
     // ---- backward ------------------------------------------------------------------------------------------------
     // [dW_mu | dW_var] = h_L^T [dmu | dv] as one GEMM
-    wg_gemm(U, 2 * O, Bt, (gcptr)hL, 1, U, (gcptr)dmu, U, 1,
+    wg_gemm(U, 2 * O, Bt, (gcptr)hL, 1, S, (gcptr)dmu, S, 1,
             GemmEpi{(gptr)(G + oWmu), O, nullptr, nullptr, 0, 0, (gptr)(G + oWv), nullptr, p.stamps, (gptr)(G + obmu), (gptr)(G + obv)},
             GemmSplit{nullptr, (gcptr)dv, 0x7fffffff, O});                    // + [db_mu | db_var] = column sums of [dmu | dv]
     // dh_L = (dmu Wmu^T + dv Wvar^T) * relu'(h_L): the relu mask rides in the epilogue of the GEMM that completes dh
     // dh_L = ([dmu | dv] [W_mu | W_var]^T) * relu'(h_L): one GEMM over K = 2O; the relu mask rides in its epilogue
-    wg_gemm(Bt, U, 2 * O, (gcptr)dmu, U, 1, (gcptr)(W + oWmu), 1, O,
-            GemmEpi{(gptr)dha, U, nullptr, (gcptr)hL, U, 0, nullptr, nullptr, p.stamps, nullptr, nullptr}, GemmSplit{(gcptr)dv, (gcptr)(W + oWv), O, 0x7fffffff});
+    wg_gemm(Bt, U, 2 * O, (gcptr)dmu, S, 1, (gcptr)(W + oWmu), 1, O,
+            GemmEpi{(gptr)dha, S, nullptr, (gcptr)hL, S, 0, nullptr, nullptr, p.stamps, nullptr, nullptr}, GemmSplit{(gcptr)dv, (gcptr)(W + oWv), O, 0x7fffffff});
     CEM_TR_STAMP(6);
     float *dcur = dha, *dnext = dhb;
     for (int l = L - 1; l >= 0; --l) {
-        const float *hin = l == 0 ? xs : hs + (size_t)(l - 1) * CEM_TROWS * U;
+        const float *hin = l == 0 ? xs : hs + (size_t)(l - 1) * CEM_TROWS * S;
         const int in = l == 0 ? D : U;
-        wg_gemm(in, U, Bt, (gcptr)hin, 1, U, (gcptr)dcur, U, 1, GemmEpi{(gptr)(G + offW(l)), U, nullptr, nullptr, 0, 0, nullptr, nullptr, p.stamps, (gptr)(G + offb(l)), nullptr}, CEM_NOSPLIT);   // dW_l = h_{l-1}^T dh_l, db_l = column sums of dh_l
+        wg_gemm(in, U, Bt, (gcptr)hin, 1, S, (gcptr)dcur, S, 1, GemmEpi{(gptr)(G + offW(l)), U, nullptr, nullptr, 0, 0, nullptr, nullptr, p.stamps, (gptr)(G + offb(l)), nullptr}, CEM_NOSPLIT);   // dW_l = h_{l-1}^T dh_l, db_l = column sums of dh_l
         if (l > 0) {
-            wg_gemm(Bt, U, U, (gcptr)dcur, U, 1, (gcptr)(W + offW(l)), 1, U, GemmEpi{(gptr)dnext, U, nullptr, (gcptr)hin, U, 0, nullptr, nullptr, p.stamps, nullptr, nullptr}, CEM_NOSPLIT);   // dh_{l-1} = (dh_l W_l^T) relu'
+            wg_gemm(Bt, U, U, (gcptr)dcur, S, 1, (gcptr)(W + offW(l)), 1, U, GemmEpi{(gptr)dnext, S, nullptr, (gcptr)hin, S, 0, nullptr, nullptr, p.stamps, nullptr, nullptr}, CEM_NOSPLIT);   // dh_{l-1} = (dh_l W_l^T) relu'
             float *t = dcur; dcur = dnext; dnext = t;
         }
     }

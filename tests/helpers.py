@@ -6,8 +6,8 @@ from oracle import cem_oracle as o
 from ethz_safe_learning_amd import PlannerConfig, ScorerConfig
 
 
-def make_problem(obs_dim=60, act_dim=2, E=5, n_layers=4, seed=1234, bias_noise=0.05, **kw):
-    pb = o.synthetic_problem(obs_dim=obs_dim, act_dim=act_dim, ensemble_size=E, units=128, n_layers=n_layers, seed=seed, **kw)
+def make_problem(obs_dim=60, act_dim=2, E=5, n_layers=4, seed=1234, bias_noise=0.05, units=128, **kw):
+    pb = o.synthetic_problem(obs_dim=obs_dim, act_dim=act_dim, ensemble_size=E, units=units, n_layers=n_layers, seed=seed, **kw)
     if bias_noise:
         rng = np.random.default_rng(seed + 999)
         for w in pb['weights']:
@@ -31,7 +31,8 @@ def configs(pb, N, H, P, E, k, I=3, variant='cem', thr=-1.0, noise=0.0, post=0.3
                                              reward_distance=sp.reward_distance, reward_goal=sp.reward_goal,
                                              reward_clip=sp.reward_clip, constrain_indicator=sp.constrain_indicator,
                                              cost_kinds=list(sp.cost_kinds)),
-                         act_low=pb['low'], act_high=pb['high'], n_layers=len(pb['weights'][0]['W']), smoothing=smoothing,
+                         act_low=pb['low'], act_high=pb['high'], n_layers=len(pb['weights'][0]['W']), units=pb['weights'][0]['W'][0].shape[1],
+                         smoothing=smoothing,
                          stddev_threshold=thr, noise_stddev=noise, variant=variant, posterior_mean_threashold=post,
                          sampling_propagation=sampling, scale_features=scale, world_size=world_size, rank=rank,
                          chunks_per_tile=chunks_per_tile, use_graph=use_graph, rollout_segments=rollout_segments, select_mode=select_mode)

@@ -830,3 +830,31 @@ def test_select_modes_agree_on_a_whole_plan():
     assert abs(res[0][1] - res[1][1]) <= 2e-5 and res[0][2] == res[1][2] and 1 < res[0][2] <= I
     assert len(np.intersect1d(res[0][3], res[1][3])) >= 0.99 * k
     np.testing.assert_allclose(res[0][4], res[1][4], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('units', [64, 100, 17])
+def test_narrow_hidden_layers_run_zero_padded(units):
+    """`units` below 128 (config/models.yaml:11 takes any value): the library pads the layers to its 128-wide kernel with zero
+    weights and biases, which adds exact zeros to every sum — scores against the fp64 oracle of the NARROW network, and a whole
+    plan against the fp32 oracle."""
+    torch = _torch()
+    pb = o.synthetic_problem(obs_dim=60, act_dim=2, ensemble_size=5, units=units, n_layers=3, seed=5)
+    for w in pb['weights']:
+        for b in w['b']:
+            b[:] = np.random.default_rng(1).normal(0, 0.05, b.shape).astype(np.float32)
+    N, H, P, E, I = 64, 7, 5, 5, 3
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=6, I=I, variant='safe', post=0.5, noise=0.01)
+    pcfg.units = units
+    pl = hp.make_planner(pb, pcfg)
+    ea, em, eo = hp.noise(I, N, H, 2, P, 60, seed=8)
+    actions, returns, scores = _run_iteration(pl, pb, ocfg, ea, em)
+    pl.plan_end()
+    ref64, traj64 = o.candidate_scores(pb['state'].astype(np.float64), actions.astype(np.float64), o.cast_weights(pb['weights'], np.float64),
+                                       pb['inputs_min'], pb['inputs_max'], em[0], ocfg, pb['scorer'], return_traj=True)
+    ok = o.threshold_margins(traj64, pb['scorer']).reshape(P, N).min(axis=0) > 1e-4
+    assert ok.mean() > 0.8 and _score_err(scores[ok], ref64[ok]) <= 1.0
+    a, s, it = pl.plan(pb['state'], eps_act=ea, eps_model=em, eps_out=eo)
+    ra, rs, rit = o.do_generate_action(pb['state'], pb['weights'], pb['inputs_min'], pb['inputs_max'], pb['low'], pb['high'],
+                                       ea, em, eo, ocfg, pb['scorer'])
+    assert it == rit and abs(s - rs) <= FULL_SIZE_ATOL
+    np.testing.assert_allclose(a, ra, rtol=1e-5, atol=1e-6)

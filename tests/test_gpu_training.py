@@ -12,8 +12,8 @@ from tests import helpers as hp
 pytestmark = pytest.mark.gpu
 
 
-def _setup(E=3, D=62, O=60, L=4, seed=0):
-    pb = hp.make_problem(O, D - O, E, L, seed=seed, bias_noise=0.05, head_scale=0.3, var_bias=-2.0)
+def _setup(E=3, D=62, O=60, L=4, seed=0, units=128):
+    pb = hp.make_problem(O, D - O, E, L, seed=seed, bias_noise=0.05, head_scale=0.3, var_bias=-2.0, units=units)
     rng = np.random.default_rng(seed)
     n = 500
     X = rng.normal(0, 0.5, (n, D)).astype(np.float32)
@@ -21,12 +21,12 @@ def _setup(E=3, D=62, O=60, L=4, seed=0):
     return pb, X, Y, rng
 
 
-@pytest.mark.parametrize('E,D,O,L,bt', [(3, 62, 60, 4, 64), (2, 8, 6, 2, 37), (2, 112, 100, 3, 64)])
-def test_training_steps_match_oracle(E, D, O, L, bt):
+@pytest.mark.parametrize('E,D,O,L,bt,units', [(3, 62, 60, 4, 64, 128), (2, 8, 6, 2, 37, 128), (2, 112, 100, 3, 64, 128), (2, 62, 60, 3, 50, 48)])
+def test_training_steps_match_oracle(E, D, O, L, bt, units):
     import torch
     from ethz_safe_learning_amd.trainer import CemTrainer
-    pb, X, Y, rng = _setup(E, D, O, L, seed=E)
-    tr = CemTrainer(D, O, 128, L, E, batch_size=64)
+    pb, X, Y, rng = _setup(E, D, O, L, seed=E, units=units)
+    tr = CemTrainer(D, O, units, L, E, batch_size=64)
     tr.set_state(pb['weights'])
     w = o.cast_weights(pb['weights'], np.float32)
     ms, vs = o.zeros_like_weights(w), o.zeros_like_weights(w)
