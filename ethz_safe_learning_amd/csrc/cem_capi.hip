@@ -2,6 +2,7 @@
 // Built with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC (see csrc/build.sh).
 #include "cem_device.h"
 #include "cem_train.h"
+#include "cem_train_tile.h"
 #include "../../include/cem_mpc.h"
 
 #include <dlfcn.h>
@@ -1149,6 +1150,7 @@ struct cem_trainer {
     char *ws; hipStream_t stream; bool own_stream;
     size_t nat, scratch_pm;
     size_t oW, oM, oV, oG, oS, oL, oP, oT, total;
+    bool tile_kernel;
 };
 
 namespace {
@@ -1178,6 +1180,26 @@ void train_layout(cem_trainer *t)
     t->oT = take(32 * sizeof(long long));            // phase stamps of -DCEM_STAMPS diagnostic builds: the LAST 256 B of the workspace
     t->total = o;
 }
+// the training step: the tile kernel (cem_train_tile.h; one instantiation per layer count up to CEM_TT_MAXL), otherwise the
+// GEMM-by-GEMM kernel (cem_train.h), which takes any depth
+template <int L>
+hipError_t tile_kernel_lds(size_t lds)
+{
+    return lds > 48 * 1024 ? hipFuncSetAttribute(reinterpret_cast<const void *>(&cem_train_tile_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) : hipSuccess;
+}
+
+void launch_train_step(const cem_trainer *t, const TrainParams &p)
+{
+    const size_t lds = (size_t)(t->cfg.n_layers + 5) * CEM_TT_NB * CEM_TT_BLK;
+    const dim3 grid(t->cfg.ensemble_size * CEM_TPARTS);
+    if (!t->tile_kernel) { hipLaunchKernelGGL(cem_train_step_kernel, grid, dim3(CEM_TNT), 0, t->stream, p); return; }
+    switch (t->cfg.n_layers) {
+#define CEM_CASE(LL) case LL: hipLaunchKernelGGL(cem_train_tile_kernel<LL>, grid, dim3(256), lds, t->stream, p); break;
+    CEM_CASE(1) CEM_CASE(2) CEM_CASE(3) CEM_CASE(4) CEM_CASE(5) CEM_CASE(6)
+#undef CEM_CASE
+    }
+}
+
 void fill_train_params(const cem_trainer *t, TrainParams &p)
 {
     const cem_train_config_t &c = t->cfg;
@@ -1215,6 +1237,17 @@ int cem_trainer_create(const cem_train_config_t *cfg, void *workspace, size_t wo
     }
     if (hipMemsetAsync(t->ws, 0, t->total, t->stream) != hipSuccess || hipStreamSynchronize(t->stream) != hipSuccess) {
         g_last_hip = (int)hipGetLastError(); delete t; return CEM_ERR_HIP;
+    }
+    {   // the tile kernel keeps every layer's activations in LDS: (n_layers + 5) x 8 KB, beyond 48 KB only with the runtime's leave
+        const size_t lds = (size_t)(cfg->n_layers + 5) * CEM_TT_NB * CEM_TT_BLK;
+        t->tile_kernel = cfg->n_layers <= CEM_TT_MAXL && std::getenv("CEM_TRAIN_GEMM_KERNEL") == nullptr;
+        hipError_t e = hipSuccess;
+        if (t->tile_kernel) switch (cfg->n_layers) {
+#define CEM_CASE(LL) case LL: e = tile_kernel_lds<LL>(lds); break;
+            CEM_CASE(1) CEM_CASE(2) CEM_CASE(3) CEM_CASE(4) CEM_CASE(5) CEM_CASE(6)
+#undef CEM_CASE
+        }
+        if (e != hipSuccess) { (void)hipGetLastError(); t->tile_kernel = false; }
     }
     *out = t;
     return CEM_OK;
@@ -1257,7 +1290,7 @@ int cem_trainer_step(cem_trainer_t *t, const float *x_dev, const float *y_dev, c
     if (perm_dev && offset + bt > nperm) return CEM_ERR_INVALID_ARG;
     TrainParams p; fill_train_params(t, p);
     p.x = x_dev; p.y = y_dev; p.perm = perm_dev; p.nperm = nperm; p.offset = offset; p.Bt = bt; p.lr_t = lr_t; p.loss_out = loss_dev; p.train = 1;
-    hipLaunchKernelGGL(cem_train_step_kernel, dim3(t->cfg.ensemble_size * CEM_TPARTS), dim3(CEM_TNT), 0, t->stream, p);
+    launch_train_step(t, p);
     const size_t n4 = (size_t)p.E * p.nat / 4;
     const unsigned adam_grid = (unsigned)std::min<size_t>(std::max<size_t>((n4 + 255) / 256, 1), 2048);
     hipLaunchKernelGGL(cem_adam_kernel, dim3(adam_grid), dim3(256), 0, t->stream, p);
@@ -1286,7 +1319,7 @@ int cem_trainer_eval(cem_trainer_t *t, const float *x_dev, const float *y_dev, i
     p.x = x_dev; p.y = y_dev; p.perm = nullptr; p.loss_out = (float *)(t->ws + t->oL); p.train = 0;
     for (int off = 0; off < n; off += t->cfg.batch_size) {
         p.offset = off; p.Bt = std::min(t->cfg.batch_size, n - off);
-        hipLaunchKernelGGL(cem_train_step_kernel, dim3(E * CEM_TPARTS), dim3(CEM_TNT), 0, t->stream, p);
+        launch_train_step(t, p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(part.data(), t->ws + t->oP, part.size() * 4, hipMemcpyDeviceToHost, t->stream));
         HIPCHK(hipStreamSynchronize(t->stream));

@@ -1,0 +1,343 @@
+// cem_train_tile.h — the ensemble training step in the style of the rollout kernel:
+// MlpEnsemble.training_step / validation_step, simba/models/mlp_ensemble.py:134-155, loss negative_log_likelihood (:64-67).
+//
+// A workgroup of 4 waves takes 16 rows of ONE member's minibatch through the forward pass, the loss and the whole backward
+// pass without leaving the CU: every product is a chain of v_mfma_f32_16x16x4_f32 on 16-feature blocks, the activations of
+// all layers stay in LDS in the accumulator layout (lane = (feature quad q, row j), register r = feature 4q + r of the block:
+// what one layer's MFMA writes IS the next layer's B operand, as in cem_rollout_kernel), and the weights are read straight
+// from their natural Keras layout ([in][out]) with per-lane addressing, so the Adam kernel keeps one copy of the weights and
+// nothing is re-packed per step.
+//   forward   h_l^T [U x rows]   = relu(W_l^T h_{l-1}^T + b_l)      A = W_l[k][out], B = h_{l-1} block
+//   heads     mu, v              = W_mu^T h_L^T + b, W_var^T h_L^T + b
+//   loss      dmu, dv, partial sums of the NLL                       elementwise on the accumulators
+//   backward  dh_{l-1}^T         = (W_l dh_l^T) * relu'(h_{l-1})      A = W_l[in][k], B = dh_l block
+//   weights   dW_l [in x out]    = h_{l-1}^T dh_l                     A, B gathered from LDS with the row as the k index
+//   biases    db_l               = sum over rows of dh_l               16-lane reductions of the accumulators
+// Each workgroup writes PARTIAL gradients (its 16 rows); the Adam kernel adds a member's parts in a fixed order.
+//
+// Weight traffic.  A stage (one layer for one wave: 2 output blocks x 8 k blocks) needs 64 words per lane and 64 MFMAs that take
+// 2 K cycles — less than one L2 round trip with nothing else in flight.  The weights do not depend on the activations, so every
+// stage's 64 loads are issued a whole stage AHEAD into a second register buffer (the layer count is a template parameter: the
+// stage sequence, and with it every register index, is fixed at compile time).  The loads are raw buffer loads: the k offset
+// lives in an SGPR, the lane offset is one VGPR per accumulator, and an out-of-range row or column block reads as zero.
+#pragma once
+#include "cem_train.h"
+
+#define CEM_TT_BLK 1024                      // bytes of one 16-feature x 16-row block in LDS: [64 lanes][4 words]
+#define CEM_TT_NB 8                          // blocks per activation matrix (128 features)
+#define CEM_TT_MAXL 6                        // layer counts with their own instantiation (the reference ships 4)
+
+struct TtCtx { int lane, q, j, w, cnt; };
+
+__device__ __forceinline__ float tt_row_sum(float v)          // sum over the 16 rows (lanes j) of a feature: fixed butterfly order
+{
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) v = v + __shfl_xor(v, d, 16);
+    return v;
+}
+
+// One weight operand of a stage: matrix W (a buffer resource over exactly its words), A(F) at MFMA step r on lane (q, j) =
+// W[(16F + 4q + r) * sk + (mb + j) * sm]: forward sk = row stride, sm = 1 (k runs down the rows); backward sk = 1, sm = row stride.
+struct TtOp {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int lane_off;                            // bytes: (4q * sk + (mb + j) * sm) * 4, or an out-of-range offset when mb + j is past the matrix
+    int sk4;                                 // bytes per k
+};
+
+__device__ __forceinline__ TtOp tt_op(const gcptr W, const int words, const int sk, const int sm, const int mb, const int Mdim, const TtCtx &c)
+{
+    TtOp o;
+    o.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>((const float *)W), 0, words * 4, 0x00020000);
+    o.lane_off = (mb + c.j < Mdim) ? (4 * c.q * sk + (mb + c.j) * sm) * 4 : 0x7fffff00;      // past the end: the load returns 0
+    o.sk4 = sk * 4;
+    return o;
+}
+
+// issue the loads of a stage: wv[F][a][r] for ALL eight k blocks, branch-free (a k block past the matrix reads zeros in the
+// forward form — its offsets are past the end of the buffer; in the backward form it may alias the next row, and the matching B
+// values are exact zeros: every LDS block past a matrix's width is kept zero)
+template <int NACC>
+__device__ __forceinline__ void tt_load(float (&wv)[CEM_TT_NB][NACC][4], const TtOp (&op)[NACC])
+{
+#pragma unroll
+    for (int F = 0; F < CEM_TT_NB; ++F)
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                wv[F][a][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(op[a].rsrc, op[a].lane_off, (16 * F + r) * op[a].sk4, 0));
+    // pin the stage's loads HERE: left alone the scheduler hoists later stages' loads as well (renaming their registers: 512 VGPRs
+    // and spills) or sinks these to their uses (one L2 round trip per k block)
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// acc[a] += sum over the eight k blocks of A_a(F) . B(F), B(F) = LDS block F of `bsrc`
+template <int NACC>
+__device__ __forceinline__ void tt_mfma(f4 (&acc)[NACC], const float (&wv)[CEM_TT_NB][NACC][4], const char *bsrc, const TtCtx &c)
+{
+#pragma unroll
+    for (int F = 0; F < CEM_TT_NB; ++F) {
+        const f4 hb = *reinterpret_cast<const f4 *>(bsrc + (F * 64 + c.lane) * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[F][a][r], hb[r], acc[a], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// element (feature j of the block, row 4P + q) of an LDS block in the accumulator layout: the operands of the dW products,
+// where the ROW is the contraction index
+__device__ __forceinline__ float tt_gather(const char *blk, const int P, const TtCtx &c)
+{
+    return *reinterpret_cast<const float *>(blk + ((16 * (c.j >> 2) + 4 * P + c.q) * 4 + (c.j & 3)) * 4);
+}
+
+// dW[in][out] partial of one layer: this wave owns the in-feature blocks Gi = 2w, 2w+1 (< nIn) and all out blocks F < nOut:
+// dW[16Gi + 4q + r][16F + j] = sum over rows.  hsrc / dsrc: LDS activations of the layer's input / the gradient of its output.
+__device__ __forceinline__ void tt_dw(const char *hsrc, const char *dsrc, const int nIn, const int inDim, const int outDim,
+                                      float *Gw, const int ldw, const TtCtx &c)
+{
+    float b[CEM_TT_NB][4];                                                    // all eight out blocks (blocks past the width hold zeros)
+#pragma unroll
+    for (int F = 0; F < CEM_TT_NB; ++F)
+#pragma unroll
+        for (int P = 0; P < 4; ++P) b[F][P] = tt_gather(dsrc + F * CEM_TT_BLK, P, c);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int Gi = 2 * c.w + g;
+        if (Gi < nIn) {                                                       // wave-uniform
+            f4 acc[CEM_TT_NB];
+#pragma unroll
+            for (int F = 0; F < CEM_TT_NB; ++F) acc[F] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int P = 0; P < 4; ++P) {
+                const float a = tt_gather(hsrc + Gi * CEM_TT_BLK, P, c);
+#pragma unroll
+                for (int F = 0; F < CEM_TT_NB; ++F) acc[F] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[F][P], acc[F], 0, 0, 0);
+            }
+#pragma unroll
+            for (int F = 0; F < CEM_TT_NB; ++F) {
+                const int n = 16 * F + c.j;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mI = 16 * Gi + 4 * c.q + r;
+                    if (mI < inDim && n < outDim) Gw[(size_t)mI * ldw + n] = acc[F][r];
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int L>
+__global__ __launch_bounds__(256) void cem_train_tile_kernel(const TrainParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char tsm[];
+    __shared__ float red[2][4];
+    __shared__ int32_t rows_s[CEM_TROWS];
+    const int m = blockIdx.x / CEM_TPARTS, part = blockIdx.x % CEM_TPARTS, tid = threadIdx.x;
+    const int D = p.D, O = p.O, U = p.U;
+    const int row0 = part * CEM_TROWS;
+    const int cnt = p.Bt - row0 < CEM_TROWS ? p.Bt - row0 : CEM_TROWS;
+    if (cnt <= 0) return;                          // a short minibatch: the Adam kernel only adds the parts that exist
+    TtCtx c; c.lane = tid & 63; c.q = c.lane >> 4; c.j = c.lane & 15; c.w = __builtin_amdgcn_readfirstlane(tid >> 6); c.cnt = cnt;
+    const gcptr W = (gcptr)(p.W + (size_t)m * p.nat);
+    float *G = p.grad + ((size_t)part * p.E + m) * p.nat;
+    // natural-blob offsets (cem_mpc.h): W_0,b_0,...,W_mu,b_mu,W_var,b_var
+    auto offW = [&](int l) { return l == 0 ? (size_t)0 : (size_t)D * U + U + (size_t)(l - 1) * ((size_t)U * U + U); };
+    auto offb = [&](int l) { return offW(l) + (size_t)(l == 0 ? D : U) * U; };
+    const size_t oWmu = (size_t)D * U + U + (size_t)(L - 1) * ((size_t)U * U + U), obmu = oWmu + (size_t)U * O;
+    const size_t oWv = obmu + O, obv = oWv + (size_t)U * O;
+    const int nbD = (D + 15) >> 4, nbU = (U + 15) >> 4, nbO = (O + 15) >> 4;
+    const bool own = 2 * c.w < nbU;                                // this wave has hidden-unit blocks 2w, 2w + 1 (wave-uniform)
+    const int mb0 = 16 * (2 * c.w), mb1 = mb0 + 16;
+    // LDS: act[0..L] (layer inputs / outputs), dh ping-pong, dmu | dv
+    char *act = tsm;                                               // [(L + 1)][8 blocks]
+    char *dbuf = tsm + (size_t)(L + 1) * CEM_TT_NB * CEM_TT_BLK;   // [2][8 blocks]
+    char *dhd = dbuf + 2 * CEM_TT_NB * CEM_TT_BLK;                 // [16 blocks]: dmu blocks 0.., dv blocks 8..
+
+    // operand descriptors of every stage (all uniform but the lane offsets)
+    float wb[2][CEM_TT_NB][2][4];                                  // two stages' worth of weights: one in use, one in flight
+    auto fwd_ops = [&](const int l, TtOp (&op)[2]) {
+        const int in = l == 0 ? D : U;
+        op[0] = tt_op(W + offW(l), in * U, U, 1, mb0, U, c); op[1] = tt_op(W + offW(l), in * U, U, 1, mb1, U, c);
+    };
+    auto head_ops = [&](const int Fo, TtOp (&op)[2]) {
+        op[0] = tt_op(W + oWmu, U * O, O, 1, 16 * Fo, O, c); op[1] = tt_op(W + oWv, U * O, O, 1, 16 * Fo, O, c);
+    };
+    auto bwd_ops = [&](const gcptr Wm, const int words, const int ld, TtOp (&op)[2]) {
+        op[0] = tt_op(Wm, words, 1, ld, mb0, U, c); op[1] = tt_op(Wm, words, 1, ld, mb1, U, c);
+    };
+    {   // the first layer's weights go out before anything else
+        TtOp op[2]; fwd_ops(0, op);
+        if (own) tt_load<2>(wb[0], op);
+    }
+
+    if (tid < CEM_TROWS) {
+        const int rr = tid < cnt ? tid : cnt - 1;                  // rows past the end repeat the last one; their gradients are masked to zero
+        rows_s[tid] = p.perm ? p.perm[(size_t)m * p.nperm + p.offset + row0 + rr] : p.offset + row0 + rr;
+    }
+    __syncthreads();
+    const int myrow = rows_s[c.j];
+    // targets of this lane's row for the head blocks this wave owns (requested now, needed after the forward pass)
+    f4 yt[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int o = 16 * (c.w + 4 * i) + 4 * c.q + r; yt[i][r] = p.y[(size_t)myrow * O + (o < O ? o : O - 1)]; }
+    // ---- h_0 = the gathered, already scaled inputs: wave w brings blocks w, w + 4 (blocks past the input width: zeros) --------
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int F = c.w + 4 * i;
+        f4 x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int f = 16 * F + 4 * c.q + r; x[r] = f < D ? p.x[(size_t)myrow * D + f] : 0.f; }
+        *reinterpret_cast<f4 *>(act + (F * 64 + c.lane) * 16) = x;
+        // the head-gradient blocks this wave would own: zero until (unless) the loss writes them
+        *reinterpret_cast<f4 *>(dhd + (F * 64 + c.lane) * 16) = (f4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f4 *>(dhd + ((CEM_TT_NB + F) * 64 + c.lane) * 16) = (f4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+
+    // ---- forward (mlp_ensemble.py:18-22,59-61): wave w computes output blocks 2w, 2w + 1 of every layer -------------------
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        // next stage's weights: the next layer, or this wave's first head block
+        if (l + 1 < L) { TtOp op[2]; fwd_ops(l + 1, op); if (own) tt_load<2>(wb[(l + 1) & 1], op); }
+        else { TtOp op[2]; head_ops(c.w, op); if (c.w < nbO) tt_load<2>(wb[(l + 1) & 1], op); }
+        f4 acc[2];
+        const gcptr bl = W + offb(l);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int o = mb0 + 16 * a + 4 * c.q + r; acc[a][r] = o < U ? bl[o] : 0.f; }
+        if (own) tt_mfma<2>(acc, wb[l & 1], act + (size_t)l * CEM_TT_NB * CEM_TT_BLK, c);
+        char *out = act + (size_t)(l + 1) * CEM_TT_NB * CEM_TT_BLK;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            f4 h = acc[a];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = (mb0 + 16 * a + 4 * c.q + r < U) ? fmaxf(h[r], 0.f) : 0.f;     // units past U stay exactly zero
+            *reinterpret_cast<f4 *>(out + ((2 * c.w + a) * 64 + c.lane) * 16) = h;
+        }
+        __syncthreads();
+    }
+    const char *hL = act + (size_t)L * CEM_TT_NB * CEM_TT_BLK;
+
+    // ---- heads (mlp_ensemble.py:33-34) + negative_log_likelihood (:64-67) and its gradients -------------------------------
+    // stage L: head block w (weights in wb[L & 1]); stage L + 1: head block w + 4
+    float s_log = 0.f, s_sq = 0.f;
+    const float ninv = 1.0f / ((float)p.Bt * (float)O * (float)p.E);       // the mean runs over the WHOLE minibatch
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int Fo = c.w + 4 * i;
+        // the stage after this one: the second head block, then the first backward stage (W_mu part of dh_L)
+        if (i == 0) { TtOp op[2]; head_ops(c.w + 4, op); if (c.w + 4 < nbO) tt_load<2>(wb[(L + 1) & 1], op); }
+        else if (p.train) { TtOp op[2]; bwd_ops(W + oWmu, U * O, O, op); if (own) tt_load<2>(wb[(L + 2) & 1], op); }
+        if (Fo < nbO) {                                                      // wave-uniform
+            f4 acc[2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int o = 16 * Fo + 4 * c.q + r; acc[0][r] = o < O ? W[obmu + o] : 0.f; acc[1][r] = o < O ? W[obv + o] : 0.f; }
+            tt_mfma<2>(acc, wb[(L + i) & 1], hL, c);
+            f4 dmu = (f4){0.f, 0.f, 0.f, 0.f}, dv = dmu;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * Fo + 4 * c.q + r;
+                const bool live = o < O && c.j < cnt;
+                const float v = acc[1][r], var = train_softplus(v) + 1e-4f;
+                const float diff = acc[0][r] - yt[i][r];
+                if (live) {
+                    s_log += logf(6.283185307179586f * var);
+                    s_sq += diff * diff / var;
+                    dmu[r] = diff / var * ninv;
+                    const float dvar = (0.5f / var - 0.5f * diff * diff / (var * var)) * ninv;
+                    dv[r] = dvar / (1.0f + expf(-v));                       // d softplus(v)/dv = sigmoid(v)
+                }
+            }
+            if (p.train) {
+                *reinterpret_cast<f4 *>(dhd + (Fo * 64 + c.lane) * 16) = dmu;
+                *reinterpret_cast<f4 *>(dhd + ((CEM_TT_NB + Fo) * 64 + c.lane) * 16) = dv;
+                // bias gradients of the heads: sums over the rows
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = 16 * Fo + 4 * c.q + r;
+                    const float a = tt_row_sum(dmu[r]), b = tt_row_sum(dv[r]);
+                    if (c.j == 0 && o < O) { G[obmu + o] = a; G[obv + o] = b; }
+                }
+            }
+        }
+    }
+    // this part's share of the two sums of the loss; the Adam kernel (training) or the host (validation) adds the parts in order
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { s_log += __shfl_xor(s_log, d); s_sq += __shfl_xor(s_sq, d); }
+    if (c.lane == 0) { red[0][c.w] = s_log; red[1][c.w] = s_sq; }
+    __syncthreads();
+    if (tid == 0) {
+        p.loss_part[((size_t)m * CEM_TPARTS + part) * 2] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+        p.loss_part[((size_t)m * CEM_TPARTS + part) * 2 + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+    }
+    if (!p.train) return;
+
+    // ---- backward ---------------------------------------------------------------------------------------------------------
+    // stage L + 2: W_mu part of dh_L (in wb[(L + 2) & 1]); stage L + 3: W_var part; stages L + 4 ...: dh of layers L-1 .. 1
+    { TtOp op[2]; bwd_ops(W + oWv, U * O, O, op); if (own) tt_load<2>(wb[(L + 3) & 1], op); }
+    // [dW_mu | dW_var] = h_L^T [dmu | dv]
+    tt_dw(hL, dhd, nbU, U, O, G + oWmu, O, c);
+    tt_dw(hL, dhd + CEM_TT_NB * CEM_TT_BLK, nbU, U, O, G + oWv, O, c);
+    // dh_L = (W_mu dmu^T + W_var dv^T) * relu'(h_L)
+    {
+        f4 acc[2] = {(f4){0.f, 0.f, 0.f, 0.f}, (f4){0.f, 0.f, 0.f, 0.f}};
+        if (own) tt_mfma<2>(acc, wb[(L + 2) & 1], dhd, c);
+        if (L > 1) { TtOp op[2]; bwd_ops(W + offW(L - 1), U * U, U, op); if (own) tt_load<2>(wb[(L + 4) & 1], op); }
+        if (own) tt_mfma<2>(acc, wb[(L + 3) & 1], dhd + CEM_TT_NB * CEM_TT_BLK, c);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const f4 h = *reinterpret_cast<const f4 *>(hL + ((2 * c.w + a) * 64 + c.lane) * 16);
+            f4 d = acc[a];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[r] = h[r] > 0.f ? d[r] : 0.f;
+            *reinterpret_cast<f4 *>(dbuf + ((2 * c.w + a) * 64 + c.lane) * 16) = d;
+            // db_{L-1}: sums over the rows
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = mb0 + 16 * a + 4 * c.q + r;
+                const float sum = tt_row_sum(d[r]);
+                if (c.j == 0 && o < U) G[offb(L - 1) + o] = sum;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int l = L - 1; l >= 0; --l) {
+        // stage index of the dh product that consumes W_l: L + 4 + (L - 1 - l)
+        const int st = L + 4 + (L - 1 - l);
+        const int cur = (L - 1 - l) & 1;
+        const int in = l == 0 ? D : U, nIn = l == 0 ? nbD : nbU;
+        const char *hin = act + (size_t)l * CEM_TT_NB * CEM_TT_BLK;
+        const char *dcur = dbuf + (size_t)cur * CEM_TT_NB * CEM_TT_BLK;
+        if (l > 1) { TtOp op[2]; bwd_ops(W + offW(l - 1), U * U, U, op); if (own) tt_load<2>(wb[(st + 1) & 1], op); }
+        tt_dw(hin, dcur, nIn, in, U, G + offW(l), U, c);                            // dW_l = h_{l-1}^T dh_l
+        if (l > 0) {
+            // dh_{l-1} = (W_l dh_l^T) * relu'(h_{l-1});  db_{l-1} = its row sums
+            f4 acc[2] = {(f4){0.f, 0.f, 0.f, 0.f}, (f4){0.f, 0.f, 0.f, 0.f}};
+            if (own) tt_mfma<2>(acc, wb[st & 1], dcur, c);
+            char *dnext = dbuf + (size_t)(cur ^ 1) * CEM_TT_NB * CEM_TT_BLK;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const f4 h = *reinterpret_cast<const f4 *>(hin + ((2 * c.w + a) * 64 + c.lane) * 16);
+                f4 d = acc[a];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[r] = h[r] > 0.f ? d[r] : 0.f;
+                *reinterpret_cast<f4 *>(dnext + ((2 * c.w + a) * 64 + c.lane) * 16) = d;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = mb0 + 16 * a + 4 * c.q + r;
+                    const float sum = tt_row_sum(d[r]);
+                    if (c.j == 0 && o < U) G[offb(l - 1) + o] = sum;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
