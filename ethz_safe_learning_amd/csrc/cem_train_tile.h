@@ -71,6 +71,23 @@ __device__ __forceinline__ void tt_load(float (&wv)[CEM_TT_NB][NACC][4], const T
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// the backward form of a stage's loads when the matrix's row length is a multiple of 4 words: the four MFMA steps r of a k block
+// are four CONSECUTIVE words of a row (sk = 1), so one 16-byte load brings what four 4-byte loads did — and those touched 16 rows
+// x 4 separate quads per instruction.  A quad past the row's end is whole (row length % 4 == 0) and only meets zero B values.
+template <int NACC>
+__device__ __forceinline__ void tt_load_rows(float (&wv)[CEM_TT_NB][NACC][4], const TtOp (&op)[NACC])
+{
+#pragma unroll
+    for (int F = 0; F < CEM_TT_NB; ++F)
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+            const f4 v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(op[a].rsrc, op[a].lane_off, 64 * F, 0));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wv[F][a][r] = v[r];
+        }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // acc[a] += sum over the eight k blocks of A_a(F) . B(F), B(F) = LDS block F of `bsrc`
 template <int NACC>
 __device__ __forceinline__ void tt_mfma(f4 (&acc)[NACC], const float (&wv)[CEM_TT_NB][NACC][4], const char *bsrc, const TtCtx &c)
@@ -98,6 +115,9 @@ __device__ __forceinline__ float tt_gather(const char *blk, const int P, const T
 __device__ __forceinline__ void tt_dw(const char *hsrc, const char *dsrc, const int nIn, const int inDim, const int outDim,
                                       float *Gw, const int ldw, const TtCtx &c)
 {
+#ifdef CEM_TT_DBG_NODW
+    return;
+#endif
     float b[CEM_TT_NB][4];                                                    // all eight out blocks (blocks past the width hold zeros)
 #pragma unroll
     for (int F = 0; F < CEM_TT_NB; ++F)
@@ -122,7 +142,11 @@ __device__ __forceinline__ void tt_dw(const char *hsrc, const char *dsrc, const 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int mI = 16 * Gi + 4 * c.q + r;
+#ifdef CEM_TT_DBG_NOSTORE
+                    if (mI < inDim && n < outDim && acc[F][r] == 123.456f) Gw[(size_t)mI * ldw + n] = acc[F][r];
+#else
                     if (mI < inDim && n < outDim) Gw[(size_t)mI * ldw + n] = acc[F][r];
+#endif
                 }
             }
         }
@@ -234,7 +258,7 @@ __global__ __launch_bounds__(256) void cem_train_tile_kernel(const TrainParams p
         const int Fo = c.w + 4 * i;
         // the stage after this one: the second head block, then the first backward stage (W_mu part of dh_L)
         if (i == 0) { TtOp op[2]; head_ops(c.w + 4, op); if (c.w + 4 < nbO) tt_load<2>(wb[(L + 1) & 1], op); }
-        else if (p.train) { TtOp op[2]; bwd_ops(W + oWmu, U * O, O, op); if (own) tt_load<2>(wb[(L + 2) & 1], op); }
+        else if (p.train) { TtOp op[2]; bwd_ops(W + oWmu, U * O, O, op); if (own) { if (O & 3) tt_load<2>(wb[(L + 2) & 1], op); else tt_load_rows<2>(wb[(L + 2) & 1], op); } }
         if (Fo < nbO) {                                                      // wave-uniform
             f4 acc[2];
 #pragma unroll
@@ -281,7 +305,7 @@ __global__ __launch_bounds__(256) void cem_train_tile_kernel(const TrainParams p
 
     // ---- backward ---------------------------------------------------------------------------------------------------------
     // stage L + 2: W_mu part of dh_L (in wb[(L + 2) & 1]); stage L + 3: W_var part; stages L + 4 ...: dh of layers L-1 .. 1
-    { TtOp op[2]; bwd_ops(W + oWv, U * O, O, op); if (own) tt_load<2>(wb[(L + 3) & 1], op); }
+    { TtOp op[2]; bwd_ops(W + oWv, U * O, O, op); if (own) { if (O & 3) tt_load<2>(wb[(L + 3) & 1], op); else tt_load_rows<2>(wb[(L + 3) & 1], op); } }
     // [dW_mu | dW_var] = h_L^T [dmu | dv]
     tt_dw(hL, dhd, nbU, U, O, G + oWmu, O, c);
     tt_dw(hL, dhd + CEM_TT_NB * CEM_TT_BLK, nbU, U, O, G + oWv, O, c);
@@ -289,7 +313,7 @@ __global__ __launch_bounds__(256) void cem_train_tile_kernel(const TrainParams p
     {
         f4 acc[2] = {(f4){0.f, 0.f, 0.f, 0.f}, (f4){0.f, 0.f, 0.f, 0.f}};
         if (own) tt_mfma<2>(acc, wb[(L + 2) & 1], dhd, c);
-        if (L > 1) { TtOp op[2]; bwd_ops(W + offW(L - 1), U * U, U, op); if (own) tt_load<2>(wb[(L + 4) & 1], op); }
+        if (L > 1) { TtOp op[2]; bwd_ops(W + offW(L - 1), U * U, U, op); if (own) { if (U & 3) tt_load<2>(wb[(L + 4) & 1], op); else tt_load_rows<2>(wb[(L + 4) & 1], op); } }
         if (own) tt_mfma<2>(acc, wb[(L + 3) & 1], dhd + CEM_TT_NB * CEM_TT_BLK, c);
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -316,7 +340,7 @@ __global__ __launch_bounds__(256) void cem_train_tile_kernel(const TrainParams p
         const int in = l == 0 ? D : U, nIn = l == 0 ? nbD : nbU;
         const char *hin = act + (size_t)l * CEM_TT_NB * CEM_TT_BLK;
         const char *dcur = dbuf + (size_t)cur * CEM_TT_NB * CEM_TT_BLK;
-        if (l > 1) { TtOp op[2]; bwd_ops(W + offW(l - 1), U * U, U, op); if (own) tt_load<2>(wb[(st + 1) & 1], op); }
+        if (l > 1) { TtOp op[2]; bwd_ops(W + offW(l - 1), U * U, U, op); if (own) { if (U & 3) tt_load<2>(wb[(st + 1) & 1], op); else tt_load_rows<2>(wb[(st + 1) & 1], op); } }
         tt_dw(hin, dcur, nIn, in, U, G + offW(l), U, c);                            // dW_l = h_{l-1}^T dh_l
         if (l > 0) {
             // dh_{l-1} = (W_l dh_l^T) * relu'(h_{l-1});  db_{l-1} = its row sums
