@@ -1194,7 +1194,7 @@ void launch_train_step(const cem_trainer *t, const TrainParams &p)
     const dim3 grid(t->cfg.ensemble_size * CEM_TPARTS);
     if (!t->tile_kernel) { hipLaunchKernelGGL(cem_train_step_kernel, grid, dim3(CEM_TNT), 0, t->stream, p); return; }
     switch (t->cfg.n_layers) {
-#define CEM_CASE(LL) case LL: hipLaunchKernelGGL(cem_train_tile_kernel<LL>, grid, dim3(256), lds, t->stream, p); break;
+#define CEM_CASE(LL) case LL: hipLaunchKernelGGL(cem_train_tile_kernel<LL>, grid, dim3(64 * CEM_TT_WAVES), lds, t->stream, p); break;
     CEM_CASE(1) CEM_CASE(2) CEM_CASE(3) CEM_CASE(4) CEM_CASE(5) CEM_CASE(6)
 #undef CEM_CASE
     }

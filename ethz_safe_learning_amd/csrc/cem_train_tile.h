@@ -1,7 +1,7 @@
 // cem_train_tile.h — the ensemble training step in the style of the rollout kernel:
 // MlpEnsemble.training_step / validation_step, simba/models/mlp_ensemble.py:134-155, loss negative_log_likelihood (:64-67).
 //
-// A workgroup of 4 waves takes 16 rows of ONE member's minibatch through the forward pass, the loss and the whole backward
+// A workgroup of 8 waves (two per SIMD: one's MFMA chain covers the other's LDS / barrier / load stalls) takes 16 rows of ONE member's minibatch through the forward pass, the loss and the whole backward
 // pass without leaving the CU: every product is a chain of v_mfma_f32_16x16x4_f32 on 16-feature blocks, the activations of
 // all layers stay in LDS in the accumulator layout (lane = (feature quad q, row j), register r = feature 4q + r of the block:
 // what one layer's MFMA writes IS the next layer's B operand, as in cem_rollout_kernel), and the weights are read straight
@@ -15,9 +15,9 @@
 //   biases    db_l               = sum over rows of dh_l               16-lane reductions of the accumulators
 // Each workgroup writes PARTIAL gradients (its 16 rows); the Adam kernel adds a member's parts in a fixed order.
 //
-// Weight traffic.  A stage (one layer for one wave: 2 output blocks x 8 k blocks) needs 64 words per lane and 64 MFMAs that take
-// 2 K cycles — less than one L2 round trip with nothing else in flight.  The weights do not depend on the activations, so every
-// stage's 64 loads are issued a whole stage AHEAD into a second register buffer (the layer count is a template parameter: the
+// Weight traffic.  A stage (one layer for one wave: 1 output block x 8 k blocks; 2 for the heads) needs 32 words per lane and 32
+// MFMAs that take 1 K cycles — less than one L2 round trip with nothing else in flight.  The weights do not depend on the activations, so every
+// stage's loads are issued a whole stage AHEAD into a second register buffer (the layer count is a template parameter: the
 // stage sequence, and with it every register index, is fixed at compile time).  The loads are raw buffer loads: the k offset
 // lives in an SGPR, the lane offset is one VGPR per accumulator, and an out-of-range row or column block reads as zero.
 #pragma once
@@ -25,14 +25,17 @@
 
 #define CEM_TT_BLK 1024                      // bytes of one 16-feature x 16-row block in LDS: [64 lanes][4 words]
 #define CEM_TT_NB 8                          // blocks per activation matrix (128 features)
+#define CEM_TT_WAVES 8                       // waves per workgroup: wave w owns 16-feature block w of every activation matrix
 #define CEM_TT_MAXL 6                        // layer counts with their own instantiation (the reference ships 4)
 
 struct TtCtx { int lane, q, j, w, cnt; };
 
-__device__ __forceinline__ float tt_row_sum(float v)          // sum over the 16 rows (lanes j) of a feature: fixed butterfly order
-{
-#pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) v = v + __shfl_xor(v, d, 16);
+__device__ __forceinline__ float tt_row_sum(float v)          // sum over the 16 rows (lanes j) of a feature: four DPP row rotations
+{                                                             // (fixed order; every lane of the row ends with the sum; no LDS traffic)
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
     return v;
 }
 
@@ -57,7 +60,7 @@ __device__ __forceinline__ TtOp tt_op(const gcptr W, const int words, const int 
 // forward form — its offsets are past the end of the buffer; in the backward form it may alias the next row, and the matching B
 // values are exact zeros: every LDS block past a matrix's width is kept zero)
 template <int NACC>
-__device__ __forceinline__ void tt_load(float (&wv)[CEM_TT_NB][NACC][4], const TtOp (&op)[NACC])
+__device__ __forceinline__ void tt_load(float (&wv)[CEM_TT_NB][2][4], const TtOp (&op)[NACC])
 {
 #pragma unroll
     for (int F = 0; F < CEM_TT_NB; ++F)
@@ -75,7 +78,7 @@ __device__ __forceinline__ void tt_load(float (&wv)[CEM_TT_NB][NACC][4], const T
 // are four CONSECUTIVE words of a row (sk = 1), so one 16-byte load brings what four 4-byte loads did — and those touched 16 rows
 // x 4 separate quads per instruction.  A quad past the row's end is whole (row length % 4 == 0) and only meets zero B values.
 template <int NACC>
-__device__ __forceinline__ void tt_load_rows(float (&wv)[CEM_TT_NB][NACC][4], const TtOp (&op)[NACC])
+__device__ __forceinline__ void tt_load_rows(float (&wv)[CEM_TT_NB][2][4], const TtOp (&op)[NACC])
 {
 #pragma unroll
     for (int F = 0; F < CEM_TT_NB; ++F)
@@ -90,7 +93,7 @@ __device__ __forceinline__ void tt_load_rows(float (&wv)[CEM_TT_NB][NACC][4], co
 
 // acc[a] += sum over the eight k blocks of A_a(F) . B(F), B(F) = LDS block F of `bsrc`
 template <int NACC>
-__device__ __forceinline__ void tt_mfma(f4 (&acc)[NACC], const float (&wv)[CEM_TT_NB][NACC][4], const char *bsrc, const TtCtx &c)
+__device__ __forceinline__ void tt_mfma(f4 (&acc)[NACC], const float (&wv)[CEM_TT_NB][2][4], const char *bsrc, const TtCtx &c)
 {
 #pragma unroll
     for (int F = 0; F < CEM_TT_NB; ++F) {
@@ -110,7 +113,7 @@ __device__ __forceinline__ float tt_gather(const char *blk, const int P, const T
     return *reinterpret_cast<const float *>(blk + ((16 * (c.j >> 2) + 4 * P + c.q) * 4 + (c.j & 3)) * 4);
 }
 
-// dW[in][out] partial of one layer: this wave owns the in-feature blocks Gi = 2w, 2w+1 (< nIn) and all out blocks F < nOut:
+// dW[in][out] partial of one layer: this wave owns the in-feature block Gi = w (< nIn) and all eight out blocks:
 // dW[16Gi + 4q + r][16F + j] = sum over rows.  hsrc / dsrc: LDS activations of the layer's input / the gradient of its output.
 __device__ __forceinline__ void tt_dw(const char *hsrc, const char *dsrc, const int nIn, const int inDim, const int outDim,
                                       float *Gw, const int ldw, const TtCtx &c)
@@ -118,36 +121,29 @@ __device__ __forceinline__ void tt_dw(const char *hsrc, const char *dsrc, const 
 #ifdef CEM_TT_DBG_NODW
     return;
 #endif
-    float b[CEM_TT_NB][4];                                                    // all eight out blocks (blocks past the width hold zeros)
+    const int Gi = c.w;
+    if (Gi < nIn) {                                                           // wave-uniform
+        f4 acc[CEM_TT_NB];
 #pragma unroll
-    for (int F = 0; F < CEM_TT_NB; ++F)
+        for (int F = 0; F < CEM_TT_NB; ++F) acc[F] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int P = 0; P < 4; ++P) b[F][P] = tt_gather(dsrc + F * CEM_TT_BLK, P, c);
+        for (int P = 0; P < 4; ++P) {
+            const float a = tt_gather(hsrc + Gi * CEM_TT_BLK, P, c);
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int Gi = 2 * c.w + g;
-        if (Gi < nIn) {                                                       // wave-uniform
-            f4 acc[CEM_TT_NB];
+            for (int F = 0; F < CEM_TT_NB; ++F)                               // out blocks past the width hold zeros
+                acc[F] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, tt_gather(dsrc + F * CEM_TT_BLK, P, c), acc[F], 0, 0, 0);
+        }
 #pragma unroll
-            for (int F = 0; F < CEM_TT_NB; ++F) acc[F] = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int F = 0; F < CEM_TT_NB; ++F) {
+            const int n = 16 * F + c.j;
 #pragma unroll
-            for (int P = 0; P < 4; ++P) {
-                const float a = tt_gather(hsrc + Gi * CEM_TT_BLK, P, c);
-#pragma unroll
-                for (int F = 0; F < CEM_TT_NB; ++F) acc[F] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[F][P], acc[F], 0, 0, 0);
-            }
-#pragma unroll
-            for (int F = 0; F < CEM_TT_NB; ++F) {
-                const int n = 16 * F + c.j;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int mI = 16 * Gi + 4 * c.q + r;
+            for (int r = 0; r < 4; ++r) {
+                const int mI = 16 * Gi + 4 * c.q + r;
 #ifdef CEM_TT_DBG_NOSTORE
-                    if (mI < inDim && n < outDim && acc[F][r] == 123.456f) Gw[(size_t)mI * ldw + n] = acc[F][r];
+                if (mI < inDim && n < outDim && acc[F][r] == 123.456f) Gw[(size_t)mI * ldw + n] = acc[F][r];
 #else
-                    if (mI < inDim && n < outDim) Gw[(size_t)mI * ldw + n] = acc[F][r];
+                if (mI < inDim && n < outDim) Gw[(size_t)mI * ldw + n] = acc[F][r];
 #endif
-                }
             }
         }
     }
@@ -155,10 +151,10 @@ __device__ __forceinline__ void tt_dw(const char *hsrc, const char *dsrc, const 
 }
 
 template <int L>
-__global__ __launch_bounds__(256) void cem_train_tile_kernel(const TrainParams p)
+__global__ __launch_bounds__(64 * CEM_TT_WAVES) void cem_train_tile_kernel(const TrainParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char tsm[];
-    __shared__ float red[2][4];
+    __shared__ float red[2][CEM_TT_WAVES];
     __shared__ int32_t rows_s[CEM_TROWS];
     const int m = blockIdx.x / CEM_TPARTS, part = blockIdx.x % CEM_TPARTS, tid = threadIdx.x;
     const int D = p.D, O = p.O, U = p.U;
@@ -174,28 +170,26 @@ __global__ __launch_bounds__(256) void cem_train_tile_kernel(const TrainParams p
     const size_t oWmu = (size_t)D * U + U + (size_t)(L - 1) * ((size_t)U * U + U), obmu = oWmu + (size_t)U * O;
     const size_t oWv = obmu + O, obv = oWv + (size_t)U * O;
     const int nbD = (D + 15) >> 4, nbU = (U + 15) >> 4, nbO = (O + 15) >> 4;
-    const bool own = 2 * c.w < nbU;                                // this wave has hidden-unit blocks 2w, 2w + 1 (wave-uniform)
-    const int mb0 = 16 * (2 * c.w), mb1 = mb0 + 16;
+    const bool own = c.w < nbU;                                    // this wave has hidden-unit block w (wave-uniform)
+    const bool ownO = c.w < nbO;                                   // ... and head block w
+    const int mb = 16 * c.w;
     // LDS: act[0..L] (layer inputs / outputs), dh ping-pong, dmu | dv
     char *act = tsm;                                               // [(L + 1)][8 blocks]
     char *dbuf = tsm + (size_t)(L + 1) * CEM_TT_NB * CEM_TT_BLK;   // [2][8 blocks]
     char *dhd = dbuf + 2 * CEM_TT_NB * CEM_TT_BLK;                 // [16 blocks]: dmu blocks 0.., dv blocks 8..
 
-    // operand descriptors of every stage (all uniform but the lane offsets)
-    float wb[2][CEM_TT_NB][2][4];                                  // two stages' worth of weights: one in use, one in flight
-    auto fwd_ops = [&](const int l, TtOp (&op)[2]) {
-        const int in = l == 0 ? D : U;
-        op[0] = tt_op(W + offW(l), in * U, U, 1, mb0, U, c); op[1] = tt_op(W + offW(l), in * U, U, 1, mb1, U, c);
-    };
-    auto head_ops = [&](const int Fo, TtOp (&op)[2]) {
-        op[0] = tt_op(W + oWmu, U * O, O, 1, 16 * Fo, O, c); op[1] = tt_op(W + oWv, U * O, O, 1, 16 * Fo, O, c);
-    };
-    auto bwd_ops = [&](const gcptr Wm, const int words, const int ld, TtOp (&op)[2]) {
-        op[0] = tt_op(Wm, words, 1, ld, mb0, U, c); op[1] = tt_op(Wm, words, 1, ld, mb1, U, c);
+    // Stage sequence (compile time): 0..L-1 the hidden layers, L the heads (mu and var of block w), L+1 / L+2 the W_mu / W_var parts
+    // of dh_L, L+3+i the dh of layer L-1-i.  Stage s's weights sit in wb[s & 1] and are requested during stage s - 1.
+    float wb[2][CEM_TT_NB][2][4];
+    auto fwd_op = [&](const int l) { return tt_op(W + offW(l), (l == 0 ? D : U) * U, U, 1, mb, U, c); };
+    auto bwd_op = [&](const gcptr Wm, const int words, const int ld) { return tt_op(Wm, words, 1, ld, mb, U, c); };
+    auto load_bwd = [&](float (&dst)[CEM_TT_NB][2][4], const gcptr Wm, const int words, const int ld) {
+        TtOp op[1] = {bwd_op(Wm, words, ld)};
+        if (own) { if (ld & 3) tt_load<1>(dst, op); else tt_load_rows<1>(dst, op); }
     };
     {   // the first layer's weights go out before anything else
-        TtOp op[2]; fwd_ops(0, op);
-        if (own) tt_load<2>(wb[0], op);
+        TtOp op[1] = {fwd_op(0)};
+        if (own) tt_load<1>(wb[0], op);
     }
 
     if (tid < CEM_TROWS) {
@@ -204,91 +198,77 @@ __global__ __launch_bounds__(256) void cem_train_tile_kernel(const TrainParams p
     }
     __syncthreads();
     const int myrow = rows_s[c.j];
-    // targets of this lane's row for the head blocks this wave owns (requested now, needed after the forward pass)
-    f4 yt[2];
+    // targets of this lane's row for the head block this wave owns (requested now, needed after the forward pass)
+    f4 yt;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int o = 16 * (c.w + 4 * i) + 4 * c.q + r; yt[i][r] = p.y[(size_t)myrow * O + (o < O ? o : O - 1)]; }
-    // ---- h_0 = the gathered, already scaled inputs: wave w brings blocks w, w + 4 (blocks past the input width: zeros) --------
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int F = c.w + 4 * i;
+    for (int r = 0; r < 4; ++r) { const int o = mb + 4 * c.q + r; yt[r] = p.y[(size_t)myrow * O + (o < O ? o : O - 1)]; }
+    // ---- h_0 = the gathered, already scaled inputs: wave w brings block w (a block past the input width: zeros) ----------------
+    {
         f4 x;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int f = 16 * F + 4 * c.q + r; x[r] = f < D ? p.x[(size_t)myrow * D + f] : 0.f; }
-        *reinterpret_cast<f4 *>(act + (F * 64 + c.lane) * 16) = x;
+        for (int r = 0; r < 4; ++r) { const int f = mb + 4 * c.q + r; x[r] = f < D ? p.x[(size_t)myrow * D + f] : 0.f; }
+        *reinterpret_cast<f4 *>(act + (c.w * 64 + c.lane) * 16) = x;
         // the head-gradient blocks this wave would own: zero until (unless) the loss writes them
-        *reinterpret_cast<f4 *>(dhd + (F * 64 + c.lane) * 16) = (f4){0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f4 *>(dhd + ((CEM_TT_NB + F) * 64 + c.lane) * 16) = (f4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f4 *>(dhd + (c.w * 64 + c.lane) * 16) = (f4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f4 *>(dhd + ((CEM_TT_NB + c.w) * 64 + c.lane) * 16) = (f4){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
 
-    // ---- forward (mlp_ensemble.py:18-22,59-61): wave w computes output blocks 2w, 2w + 1 of every layer -------------------
+    // ---- forward (mlp_ensemble.py:18-22,59-61): wave w computes output block w of every layer ----------------------------------
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-        // next stage's weights: the next layer, or this wave's first head block
-        if (l + 1 < L) { TtOp op[2]; fwd_ops(l + 1, op); if (own) tt_load<2>(wb[(l + 1) & 1], op); }
-        else { TtOp op[2]; head_ops(c.w, op); if (c.w < nbO) tt_load<2>(wb[(l + 1) & 1], op); }
-        f4 acc[2];
+        // next stage's weights: the next layer, or this wave's head block (mu and var)
+        if (l + 1 < L) { TtOp op[1] = {fwd_op(l + 1)}; if (own) tt_load<1>(wb[(l + 1) & 1], op); }
+        else {
+            TtOp op[2] = {tt_op(W + oWmu, U * O, O, 1, mb, O, c), tt_op(W + oWv, U * O, O, 1, mb, O, c)};
+            if (ownO) tt_load<2>(wb[(l + 1) & 1], op);
+        }
+        f4 acc[1];
         const gcptr bl = W + offb(l);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int r = 0; r < 4; ++r) { const int o = mb + 4 * c.q + r; acc[0][r] = o < U ? bl[o] : 0.f; }
+        if (own) tt_mfma<1>(acc, wb[l & 1], act + (size_t)l * CEM_TT_NB * CEM_TT_BLK, c);
+        f4 h = acc[0];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const int o = mb0 + 16 * a + 4 * c.q + r; acc[a][r] = o < U ? bl[o] : 0.f; }
-        if (own) tt_mfma<2>(acc, wb[l & 1], act + (size_t)l * CEM_TT_NB * CEM_TT_BLK, c);
-        char *out = act + (size_t)(l + 1) * CEM_TT_NB * CEM_TT_BLK;
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            f4 h = acc[a];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = (mb0 + 16 * a + 4 * c.q + r < U) ? fmaxf(h[r], 0.f) : 0.f;     // units past U stay exactly zero
-            *reinterpret_cast<f4 *>(out + ((2 * c.w + a) * 64 + c.lane) * 16) = h;
-        }
+        for (int r = 0; r < 4; ++r) h[r] = (mb + 4 * c.q + r < U) ? fmaxf(h[r], 0.f) : 0.f;     // units past U stay exactly zero
+        *reinterpret_cast<f4 *>(act + (size_t)(l + 1) * CEM_TT_NB * CEM_TT_BLK + (c.w * 64 + c.lane) * 16) = h;
         __syncthreads();
     }
     const char *hL = act + (size_t)L * CEM_TT_NB * CEM_TT_BLK;
 
-    // ---- heads (mlp_ensemble.py:33-34) + negative_log_likelihood (:64-67) and its gradients -------------------------------
-    // stage L: head block w (weights in wb[L & 1]); stage L + 1: head block w + 4
+    // ---- heads (mlp_ensemble.py:33-34) + negative_log_likelihood (:64-67) and its gradients: stage L ----------------------------
     float s_log = 0.f, s_sq = 0.f;
     const float ninv = 1.0f / ((float)p.Bt * (float)O * (float)p.E);       // the mean runs over the WHOLE minibatch
+    if (p.train) load_bwd(wb[(L + 1) & 1], W + oWmu, U * O, O);            // stage L + 1: the W_mu part of dh_L
+    if (ownO) {                                                            // wave-uniform
+        f4 acc[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int Fo = c.w + 4 * i;
-        // the stage after this one: the second head block, then the first backward stage (W_mu part of dh_L)
-        if (i == 0) { TtOp op[2]; head_ops(c.w + 4, op); if (c.w + 4 < nbO) tt_load<2>(wb[(L + 1) & 1], op); }
-        else if (p.train) { TtOp op[2]; bwd_ops(W + oWmu, U * O, O, op); if (own) { if (O & 3) tt_load<2>(wb[(L + 2) & 1], op); else tt_load_rows<2>(wb[(L + 2) & 1], op); } }
-        if (Fo < nbO) {                                                      // wave-uniform
-            f4 acc[2];
+        for (int r = 0; r < 4; ++r) { const int o = mb + 4 * c.q + r; acc[0][r] = o < O ? W[obmu + o] : 0.f; acc[1][r] = o < O ? W[obv + o] : 0.f; }
+        tt_mfma<2>(acc, wb[L & 1], hL, c);
+        f4 dmu = (f4){0.f, 0.f, 0.f, 0.f}, dv = dmu;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const int o = 16 * Fo + 4 * c.q + r; acc[0][r] = o < O ? W[obmu + o] : 0.f; acc[1][r] = o < O ? W[obv + o] : 0.f; }
-            tt_mfma<2>(acc, wb[(L + i) & 1], hL, c);
-            f4 dmu = (f4){0.f, 0.f, 0.f, 0.f}, dv = dmu;
+        for (int r = 0; r < 4; ++r) {
+            const int o = mb + 4 * c.q + r;
+            const bool live = o < O && c.j < cnt;
+            const float v = acc[1][r], var = train_softplus(v) + 1e-4f;
+            const float diff = acc[0][r] - yt[r];
+            if (live) {
+                s_log += logf(6.283185307179586f * var);
+                s_sq += diff * diff / var;
+                dmu[r] = diff / var * ninv;
+                const float dvar = (0.5f / var - 0.5f * diff * diff / (var * var)) * ninv;
+                dv[r] = dvar / (1.0f + expf(-v));                           // d softplus(v)/dv = sigmoid(v)
+            }
+        }
+        if (p.train) {
+            *reinterpret_cast<f4 *>(dhd + (c.w * 64 + c.lane) * 16) = dmu;
+            *reinterpret_cast<f4 *>(dhd + ((CEM_TT_NB + c.w) * 64 + c.lane) * 16) = dv;
+            // bias gradients of the heads: sums over the rows
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int o = 16 * Fo + 4 * c.q + r;
-                const bool live = o < O && c.j < cnt;
-                const float v = acc[1][r], var = train_softplus(v) + 1e-4f;
-                const float diff = acc[0][r] - yt[i][r];
-                if (live) {
-                    s_log += logf(6.283185307179586f * var);
-                    s_sq += diff * diff / var;
-                    dmu[r] = diff / var * ninv;
-                    const float dvar = (0.5f / var - 0.5f * diff * diff / (var * var)) * ninv;
-                    dv[r] = dvar / (1.0f + expf(-v));                       // d softplus(v)/dv = sigmoid(v)
-                }
-            }
-            if (p.train) {
-                *reinterpret_cast<f4 *>(dhd + (Fo * 64 + c.lane) * 16) = dmu;
-                *reinterpret_cast<f4 *>(dhd + ((CEM_TT_NB + Fo) * 64 + c.lane) * 16) = dv;
-                // bias gradients of the heads: sums over the rows
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = 16 * Fo + 4 * c.q + r;
-                    const float a = tt_row_sum(dmu[r]), b = tt_row_sum(dv[r]);
-                    if (c.j == 0 && o < O) { G[obmu + o] = a; G[obv + o] = b; }
-                }
+                const int o = mb + 4 * c.q + r;
+                const float a = tt_row_sum(dmu[r]), b = tt_row_sum(dv[r]);
+                if (c.j == 0 && o < O) { G[obmu + o] = a; G[obv + o] = b; }
             }
         }
     }
@@ -298,70 +278,65 @@ __global__ __launch_bounds__(256) void cem_train_tile_kernel(const TrainParams p
     if (c.lane == 0) { red[0][c.w] = s_log; red[1][c.w] = s_sq; }
     __syncthreads();
     if (tid == 0) {
-        p.loss_part[((size_t)m * CEM_TPARTS + part) * 2] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
-        p.loss_part[((size_t)m * CEM_TPARTS + part) * 2 + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        float a = red[0][0], b = red[1][0];
+#pragma unroll
+        for (int w = 1; w < CEM_TT_WAVES; ++w) { a += red[0][w]; b += red[1][w]; }
+        p.loss_part[((size_t)m * CEM_TPARTS + part) * 2] = a;
+        p.loss_part[((size_t)m * CEM_TPARTS + part) * 2 + 1] = b;
     }
     if (!p.train) return;
 
     // ---- backward ---------------------------------------------------------------------------------------------------------
-    // stage L + 2: W_mu part of dh_L (in wb[(L + 2) & 1]); stage L + 3: W_var part; stages L + 4 ...: dh of layers L-1 .. 1
-    { TtOp op[2]; bwd_ops(W + oWv, U * O, O, op); if (own) { if (O & 3) tt_load<2>(wb[(L + 3) & 1], op); else tt_load_rows<2>(wb[(L + 3) & 1], op); } }
-    // [dW_mu | dW_var] = h_L^T [dmu | dv]
-    tt_dw(hL, dhd, nbU, U, O, G + oWmu, O, c);
-    tt_dw(hL, dhd + CEM_TT_NB * CEM_TT_BLK, nbU, U, O, G + oWv, O, c);
+    load_bwd(wb[(L + 2) & 1], W + oWv, U * O, O);                           // stage L + 2: the W_var part of dh_L
     // dh_L = (W_mu dmu^T + W_var dv^T) * relu'(h_L)
     {
-        f4 acc[2] = {(f4){0.f, 0.f, 0.f, 0.f}, (f4){0.f, 0.f, 0.f, 0.f}};
-        if (own) tt_mfma<2>(acc, wb[(L + 2) & 1], dhd, c);
-        if (L > 1) { TtOp op[2]; bwd_ops(W + offW(L - 1), U * U, U, op); if (own) { if (U & 3) tt_load<2>(wb[(L + 4) & 1], op); else tt_load_rows<2>(wb[(L + 4) & 1], op); } }
-        if (own) tt_mfma<2>(acc, wb[(L + 3) & 1], dhd + CEM_TT_NB * CEM_TT_BLK, c);
+        f4 acc[1] = {(f4){0.f, 0.f, 0.f, 0.f}};
+        if (own) tt_mfma<1>(acc, wb[(L + 1) & 1], dhd, c);
+        if (L > 1) load_bwd(wb[(L + 3) & 1], W + offW(L - 1), U * U, U);    // stage L + 3: dh_{L-1}
+        if (own) tt_mfma<1>(acc, wb[(L + 2) & 1], dhd + CEM_TT_NB * CEM_TT_BLK, c);
+        const f4 h = *reinterpret_cast<const f4 *>(hL + (c.w * 64 + c.lane) * 16);
+        f4 d = acc[0];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const f4 h = *reinterpret_cast<const f4 *>(hL + ((2 * c.w + a) * 64 + c.lane) * 16);
-            f4 d = acc[a];
+        for (int r = 0; r < 4; ++r) d[r] = h[r] > 0.f ? d[r] : 0.f;
+        *reinterpret_cast<f4 *>(dbuf + (c.w * 64 + c.lane) * 16) = d;
+        // db_{L-1}: sums over the rows
 #pragma unroll
-            for (int r = 0; r < 4; ++r) d[r] = h[r] > 0.f ? d[r] : 0.f;
-            *reinterpret_cast<f4 *>(dbuf + ((2 * c.w + a) * 64 + c.lane) * 16) = d;
-            // db_{L-1}: sums over the rows
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = mb0 + 16 * a + 4 * c.q + r;
-                const float sum = tt_row_sum(d[r]);
-                if (c.j == 0 && o < U) G[offb(L - 1) + o] = sum;
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int o = mb + 4 * c.q + r;
+            const float sum = tt_row_sum(d[r]);
+            if (c.j == 0 && o < U) G[offb(L - 1) + o] = sum;
         }
     }
+    // [dW_mu | dW_var] = h_L^T [dmu | dv]: off the dh chain's critical path (the other wave of the SIMD runs ahead meanwhile)
+    tt_dw(hL, dhd, nbU, U, O, G + oWmu, O, c);
+    tt_dw(hL, dhd + CEM_TT_NB * CEM_TT_BLK, nbU, U, O, G + oWv, O, c);
     __syncthreads();
 #pragma unroll
     for (int l = L - 1; l >= 0; --l) {
-        // stage index of the dh product that consumes W_l: L + 4 + (L - 1 - l)
-        const int st = L + 4 + (L - 1 - l);
+        const int st = L + 3 + (L - 1 - l);                                 // the stage that consumes W_l
         const int cur = (L - 1 - l) & 1;
         const int in = l == 0 ? D : U, nIn = l == 0 ? nbD : nbU;
         const char *hin = act + (size_t)l * CEM_TT_NB * CEM_TT_BLK;
         const char *dcur = dbuf + (size_t)cur * CEM_TT_NB * CEM_TT_BLK;
-        if (l > 1) { TtOp op[2]; bwd_ops(W + offW(l - 1), U * U, U, op); if (own) { if (U & 3) tt_load<2>(wb[(st + 1) & 1], op); else tt_load_rows<2>(wb[(st + 1) & 1], op); } }
-        tt_dw(hin, dcur, nIn, in, U, G + offW(l), U, c);                            // dW_l = h_{l-1}^T dh_l
+        if (l > 1) load_bwd(wb[(st + 1) & 1], W + offW(l - 1), U * U, U);
         if (l > 0) {
             // dh_{l-1} = (W_l dh_l^T) * relu'(h_{l-1});  db_{l-1} = its row sums
-            f4 acc[2] = {(f4){0.f, 0.f, 0.f, 0.f}, (f4){0.f, 0.f, 0.f, 0.f}};
-            if (own) tt_mfma<2>(acc, wb[st & 1], dcur, c);
+            f4 acc[1] = {(f4){0.f, 0.f, 0.f, 0.f}};
+            if (own) tt_mfma<1>(acc, wb[st & 1], dcur, c);
             char *dnext = dbuf + (size_t)(cur ^ 1) * CEM_TT_NB * CEM_TT_BLK;
+            const f4 h = *reinterpret_cast<const f4 *>(hin + (c.w * 64 + c.lane) * 16);
+            f4 d = acc[0];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const f4 h = *reinterpret_cast<const f4 *>(hin + ((2 * c.w + a) * 64 + c.lane) * 16);
-                f4 d = acc[a];
+            for (int r = 0; r < 4; ++r) d[r] = h[r] > 0.f ? d[r] : 0.f;
+            *reinterpret_cast<f4 *>(dnext + (c.w * 64 + c.lane) * 16) = d;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) d[r] = h[r] > 0.f ? d[r] : 0.f;
-                *reinterpret_cast<f4 *>(dnext + ((2 * c.w + a) * 64 + c.lane) * 16) = d;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = mb0 + 16 * a + 4 * c.q + r;
-                    const float sum = tt_row_sum(d[r]);
-                    if (c.j == 0 && o < U) G[offb(l - 1) + o] = sum;
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int o = mb + 4 * c.q + r;
+                const float sum = tt_row_sum(d[r]);
+                if (c.j == 0 && o < U) G[offb(l - 1) + o] = sum;
             }
-            __syncthreads();
         }
+        tt_dw(hin, dcur, nIn, in, U, G + offW(l), U, c);                    // dW_l = h_{l-1}^T dh_l
+        if (l > 0) __syncthreads();
     }
 }
