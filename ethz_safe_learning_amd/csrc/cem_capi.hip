@@ -1175,7 +1175,7 @@ void train_layout(cem_trainer *t)
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
     t->oW = take(t->nat * c.ensemble_size * 4); t->oM = take(t->nat * c.ensemble_size * 4); t->oV = take(t->nat * c.ensemble_size * 4);
-    t->oG = take(t->nat * c.ensemble_size * CEM_TPARTS * 4); t->oS = take(t->scratch_pm * c.ensemble_size * CEM_TPARTS * 4);
+    t->oG = take(((t->nat * c.ensemble_size + 3) & ~(size_t)3) * CEM_TPARTS * 4); t->oS = take(t->scratch_pm * c.ensemble_size * CEM_TPARTS * 4);
     t->oL = take((size_t)c.ensemble_size * 4); t->oP = take((size_t)c.ensemble_size * CEM_TPARTS * 2 * 4);
     t->oT = take(32 * sizeof(long long));            // phase stamps of -DCEM_STAMPS diagnostic builds: the LAST 256 B of the workspace
     t->total = o;
@@ -1208,6 +1208,7 @@ void fill_train_params(const cem_trainer *t, TrainParams &p)
     p.grad = (float *)(t->ws + t->oG); p.scratch = (float *)(t->ws + t->oS); p.loss_part = (float *)(t->ws + t->oP);
     p.D = c.inputs_dim; p.O = c.outputs_dim; p.U = c.units; p.L = c.n_layers; p.E = c.ensemble_size;
     p.nat = (uint32_t)t->nat; p.scratch_per_member = (uint32_t)t->scratch_pm;
+    p.gpart = (uint32_t)((t->nat * c.ensemble_size + 3) & ~(size_t)3);
     p.beta1 = c.beta1; p.beta2 = c.beta2; p.eps = c.epsilon; p.clip = c.clipvalue;
     p.stamps = (long long *)(t->ws + t->oT);
 }

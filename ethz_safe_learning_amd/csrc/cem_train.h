@@ -21,14 +21,15 @@
 
 struct TrainParams {
     float *W, *Mo, *Vo;          // [E][nat] weights, Adam first / second moments (natural blob layout of cem_mpc.h)
-    float *grad;                 // [CEM_TPARTS][E][nat] partial gradients of the row parts
+    float *grad;                 // [CEM_TPARTS][gpart] partial gradients of the row parts, each [E][nat] (gpart = E * nat rounded up to
+                                 // a multiple of 4 floats: the Adam kernel reads every part with 16-byte loads)
     float *loss_part;            // [E][CEM_TPARTS][2] partial sums of the loss (log term, squared term)
     float *scratch;              // [E * CEM_TPARTS][scratch_per_member]
     const float *x, *y;          // [n][D] scaled inputs, [n][O] targets (next_obs - obs)
     const int32_t *perm;         // [E][nperm] bootstrap shuffles (mlp_ensemble.py:172-173) or nullptr (rows offset.. directly)
     int32_t nperm, offset, Bt;
     int32_t D, O, U, L, E;
-    uint32_t nat, scratch_per_member;
+    uint32_t nat, scratch_per_member, gpart;
     float lr_t, beta1, beta2, eps, clip;
     float *loss_out;             // train: [E] loss share of each member; eval: [E][2] raw sums (log term, squared term)
     int32_t train;
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
     const int row0 = part * CEM_TROWS;
     const int Bt = p.Bt - row0 < CEM_TROWS ? p.Bt - row0 : CEM_TROWS;
     if (Bt <= 0) return;                          // a short minibatch: the Adam kernel only adds the parts that exist
-    float *W = p.W + (size_t)m * p.nat, *G = p.grad + ((size_t)part * p.E + m) * p.nat;
+    float *W = p.W + (size_t)m * p.nat, *G = p.grad + (size_t)part * p.gpart + (size_t)m * p.nat;
     float *sc = p.scratch + (size_t)blockIdx.x * p.scratch_per_member;
     // scratch carve: every activation matrix has row stride S = CEM_TS (D, O, U <= 128; units below 128 leave columns unused)
     constexpr int S = CEM_TS;
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(256) void cem_adam_kernel(const TrainParams p)
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (size_t)gridDim.x * 256) {
         float4 gp[CEM_TPARTS];
 #pragma unroll
-        for (int q = 0; q < CEM_TPARTS; ++q) gp[q] = G4[(q < nparts ? (size_t)q : 0) * n4 + e];      // all parts' loads in flight at once
+        for (int q = 0; q < CEM_TPARTS; ++q) gp[q] = G4[(q < nparts ? (size_t)q : 0) * (p.gpart / 4) + e];      // all parts' loads in flight at once
         float4 g = gp[0];                                            // dW = sum over the row parts, part 0 first: a fixed order
 #pragma unroll
         for (int q = 1; q < CEM_TPARTS; ++q)
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(256) void cem_adam_kernel(const TrainParams p)
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t e = n4 * 4 + threadIdx.x;
         float g = p.grad[e];
-        for (int q = 1; q < nparts; ++q) g = g + p.grad[(size_t)q * n + e];
+        for (int q = 1; q < nparts; ++q) g = g + p.grad[(size_t)q * p.gpart + e];
         upd(g, p.Mo[e], p.Vo[e], p.W[e]);
     }
     // training_step's return value, per member: negative_log_likelihood / ensemble_size (mlp_ensemble.py:64-67,139-141)

@@ -23,7 +23,10 @@
 #pragma once
 #include "cem_train.h"
 
-#define CEM_TT_BLK 1024                      // bytes of one 16-feature x 16-row block in LDS: [64 lanes][4 words]
+#define CEM_TT_BLK 1152                      // bytes of one 16-feature x 16-row block in LDS: [4 feature quads][16 rows][4 words], each
+                                             // quad's 256 B followed by 32 B of padding: the dW products read a block TRANSPOSED (lane =
+                                             // (row quad, feature)), and without the skew the four feature quads of a row share a bank
+#define CEM_TT_LANE(c) ((c).lane * 16 + (c).q * 32)      // byte offset of lane (q, j)'s four words inside a block
 #define CEM_TT_NB 8                          // blocks per activation matrix (128 features)
 #define CEM_TT_WAVES 8                       // waves per workgroup: wave w owns 16-feature block w of every activation matrix
 #define CEM_TT_MAXL 6                        // layer counts with their own instantiation (the reference ships 4)
@@ -97,7 +100,7 @@ __device__ __forceinline__ void tt_mfma(f4 (&acc)[NACC], const float (&wv)[CEM_T
 {
 #pragma unroll
     for (int F = 0; F < CEM_TT_NB; ++F) {
-        const f4 hb = *reinterpret_cast<const f4 *>(bsrc + (F * 64 + c.lane) * 16);
+        const f4 hb = *reinterpret_cast<const f4 *>(bsrc + F * CEM_TT_BLK + CEM_TT_LANE(c));
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -110,7 +113,7 @@ __device__ __forceinline__ void tt_mfma(f4 (&acc)[NACC], const float (&wv)[CEM_T
 // where the ROW is the contraction index
 __device__ __forceinline__ float tt_gather(const char *blk, const int P, const TtCtx &c)
 {
-    return *reinterpret_cast<const float *>(blk + ((16 * (c.j >> 2) + 4 * P + c.q) * 4 + (c.j & 3)) * 4);
+    return *reinterpret_cast<const float *>(blk + (c.j >> 2) * 288 + ((4 * P + c.q) * 4 + (c.j & 3)) * 4);
 }
 
 // dW[in][out] partial of one layer: this wave owns the in-feature block Gi = w (< nIn) and all eight out blocks:
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(64 * CEM_TT_WAVES) void cem_train_tile_kernel(const
     if (cnt <= 0) return;                          // a short minibatch: the Adam kernel only adds the parts that exist
     TtCtx c; c.lane = tid & 63; c.q = c.lane >> 4; c.j = c.lane & 15; c.w = __builtin_amdgcn_readfirstlane(tid >> 6); c.cnt = cnt;
     const gcptr W = (gcptr)(p.W + (size_t)m * p.nat);
-    float *G = p.grad + ((size_t)part * p.E + m) * p.nat;
+    float *G = p.grad + (size_t)part * p.gpart + (size_t)m * p.nat;
     // natural-blob offsets (cem_mpc.h): W_0,b_0,...,W_mu,b_mu,W_var,b_var
     auto offW = [&](int l) { return l == 0 ? (size_t)0 : (size_t)D * U + U + (size_t)(l - 1) * ((size_t)U * U + U); };
     auto offb = [&](int l) { return offW(l) + (size_t)(l == 0 ? D : U) * U; };
@@ -207,10 +210,10 @@ __global__ __launch_bounds__(64 * CEM_TT_WAVES) void cem_train_tile_kernel(const
         f4 x;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const int f = mb + 4 * c.q + r; x[r] = f < D ? p.x[(size_t)myrow * D + f] : 0.f; }
-        *reinterpret_cast<f4 *>(act + (c.w * 64 + c.lane) * 16) = x;
+        *reinterpret_cast<f4 *>(act + c.w * CEM_TT_BLK + CEM_TT_LANE(c)) = x;
         // the head-gradient blocks this wave would own: zero until (unless) the loss writes them
-        *reinterpret_cast<f4 *>(dhd + (c.w * 64 + c.lane) * 16) = (f4){0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f4 *>(dhd + ((CEM_TT_NB + c.w) * 64 + c.lane) * 16) = (f4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f4 *>(dhd + c.w * CEM_TT_BLK + CEM_TT_LANE(c)) = (f4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f4 *>(dhd + (CEM_TT_NB + c.w) * CEM_TT_BLK + CEM_TT_LANE(c)) = (f4){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
 
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(64 * CEM_TT_WAVES) void cem_train_tile_kernel(const
         f4 h = acc[0];
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[r] = (mb + 4 * c.q + r < U) ? fmaxf(h[r], 0.f) : 0.f;     // units past U stay exactly zero
-        *reinterpret_cast<f4 *>(act + (size_t)(l + 1) * CEM_TT_NB * CEM_TT_BLK + (c.w * 64 + c.lane) * 16) = h;
+        *reinterpret_cast<f4 *>(act + (size_t)(l + 1) * CEM_TT_NB * CEM_TT_BLK + c.w * CEM_TT_BLK + CEM_TT_LANE(c)) = h;
         __syncthreads();
     }
     const char *hL = act + (size_t)L * CEM_TT_NB * CEM_TT_BLK;
@@ -261,8 +264,8 @@ __global__ __launch_bounds__(64 * CEM_TT_WAVES) void cem_train_tile_kernel(const
             }
         }
         if (p.train) {
-            *reinterpret_cast<f4 *>(dhd + (c.w * 64 + c.lane) * 16) = dmu;
-            *reinterpret_cast<f4 *>(dhd + ((CEM_TT_NB + c.w) * 64 + c.lane) * 16) = dv;
+            *reinterpret_cast<f4 *>(dhd + c.w * CEM_TT_BLK + CEM_TT_LANE(c)) = dmu;
+            *reinterpret_cast<f4 *>(dhd + (CEM_TT_NB + c.w) * CEM_TT_BLK + CEM_TT_LANE(c)) = dv;
             // bias gradients of the heads: sums over the rows
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -294,11 +297,11 @@ __global__ __launch_bounds__(64 * CEM_TT_WAVES) void cem_train_tile_kernel(const
         if (own) tt_mfma<1>(acc, wb[(L + 1) & 1], dhd, c);
         if (L > 1) load_bwd(wb[(L + 3) & 1], W + offW(L - 1), U * U, U);    // stage L + 3: dh_{L-1}
         if (own) tt_mfma<1>(acc, wb[(L + 2) & 1], dhd + CEM_TT_NB * CEM_TT_BLK, c);
-        const f4 h = *reinterpret_cast<const f4 *>(hL + (c.w * 64 + c.lane) * 16);
+        const f4 h = *reinterpret_cast<const f4 *>(hL + c.w * CEM_TT_BLK + CEM_TT_LANE(c));
         f4 d = acc[0];
 #pragma unroll
         for (int r = 0; r < 4; ++r) d[r] = h[r] > 0.f ? d[r] : 0.f;
-        *reinterpret_cast<f4 *>(dbuf + (c.w * 64 + c.lane) * 16) = d;
+        *reinterpret_cast<f4 *>(dbuf + c.w * CEM_TT_BLK + CEM_TT_LANE(c)) = d;
         // db_{L-1}: sums over the rows
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -324,11 +327,11 @@ __global__ __launch_bounds__(64 * CEM_TT_WAVES) void cem_train_tile_kernel(const
             f4 acc[1] = {(f4){0.f, 0.f, 0.f, 0.f}};
             if (own) tt_mfma<1>(acc, wb[st & 1], dcur, c);
             char *dnext = dbuf + (size_t)(cur ^ 1) * CEM_TT_NB * CEM_TT_BLK;
-            const f4 h = *reinterpret_cast<const f4 *>(hin + (c.w * 64 + c.lane) * 16);
+            const f4 h = *reinterpret_cast<const f4 *>(hin + c.w * CEM_TT_BLK + CEM_TT_LANE(c));
             f4 d = acc[0];
 #pragma unroll
             for (int r = 0; r < 4; ++r) d[r] = h[r] > 0.f ? d[r] : 0.f;
-            *reinterpret_cast<f4 *>(dnext + (c.w * 64 + c.lane) * 16) = d;
+            *reinterpret_cast<f4 *>(dnext + c.w * CEM_TT_BLK + CEM_TT_LANE(c)) = d;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = mb + 4 * c.q + r;

@@ -21,10 +21,23 @@ def _setup(E=3, D=62, O=60, L=4, seed=0, units=128):
     return pb, X, Y, rng
 
 
-@pytest.mark.parametrize('E,D,O,L,bt,units', [(3, 62, 60, 4, 64, 128), (2, 8, 6, 2, 37, 128), (2, 112, 100, 3, 64, 128), (2, 62, 60, 3, 50, 48)])
-def test_training_steps_match_oracle(E, D, O, L, bt, units):
+# shapes: the shipped one; narrow everything with a ragged minibatch (O % 4 != 0: 4-byte backward loads); wide observations;
+# narrow units; one layer with units % 4 != 0; six layers (the deepest tile-kernel instantiation); seven layers (beyond it: the
+# GEMM kernel whatever is asked); a minibatch shorter than one 16-row part
+SHAPES = [(3, 62, 60, 4, 64, 128), (2, 8, 6, 2, 37, 128), (2, 112, 100, 3, 64, 128), (2, 62, 60, 3, 50, 48), (2, 20, 17, 1, 64, 17),
+          (1, 62, 60, 6, 64, 100), (1, 30, 28, 7, 20, 64), (2, 62, 60, 4, 9, 128)]
+
+
+@pytest.mark.parametrize('kernel', ['tile', 'gemm'])
+@pytest.mark.parametrize('E,D,O,L,bt,units', SHAPES)
+def test_training_steps_match_oracle(E, D, O, L, bt, units, kernel, monkeypatch):
     import torch
     from ethz_safe_learning_amd.trainer import CemTrainer
+    # cem_trainer_create reads the switch: the rollout-style tile kernel (default) or the GEMM-by-GEMM kernel it replaced
+    if kernel == 'gemm':
+        monkeypatch.setenv('CEM_TRAIN_GEMM_KERNEL', '1')
+    else:
+        monkeypatch.delenv('CEM_TRAIN_GEMM_KERNEL', raising=False)
     pb, X, Y, rng = _setup(E, D, O, L, seed=E, units=units)
     tr = CemTrainer(D, O, units, L, E, batch_size=64)
     tr.set_state(pb['weights'])
