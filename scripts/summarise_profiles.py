@@ -4,6 +4,8 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 out = sys.argv[1]
+workload = sys.argv[2] if len(sys.argv) > 2 else 'B2'
+cmd = sys.argv[3] if len(sys.argv) > 3 else 'bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-graph'
 # 1. kernel stats: copy the rocprofv3 summary as is
 for f in glob.glob(os.path.join(out, 'stats', '**', '*kernel_stats.csv'), recursive=True):
     open(os.path.join(out, 'summary_kernel_stats.csv'), 'w').write(open(f).read())
@@ -22,7 +24,7 @@ for d in sorted(glob.glob(os.path.join(out, 'pmc_*'))):
             continue
         rows.append((kern, ctr, n, s / n, os.path.basename(d)))
 with open(os.path.join(out, 'summary_pmc.csv'), 'w') as fh:
-    fh.write('# scripts/collect_profiles.sh: separate rocprofv3 --kernel-trace --pmc passes of `bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-graph`\n')
+    fh.write('# separate rocprofv3 --kernel-trace --pmc passes of `%s` (workload %s)\n' % (cmd, workload))
     fh.write('# FETCH_SIZE / WRITE_SIZE in KB; on gfx950 FETCH_SIZE counts a 128-B request as 64 B -> x2 (MI355X_MICROARCH.md); SQ_*_CYCLES of waves are quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles\n')
     fh.write('kernel,counter,dispatches,mean_per_dispatch,pass\n')
     for r in rows:
@@ -31,11 +33,11 @@ roll = {c: m for k, c, n, m, p in rows if 'cem_rollout_' in k}
 kern = next((k for k, c, n, m, p in rows if 'cem_rollout_' in k), None)
 if roll:
     hit, miss = roll.get('TCC_HIT_sum', 0.0), roll.get('TCC_MISS_sum', 0.0)
-    t = {'kernel': kern, 'workload': 'B2', 'fetch_size_kb': roll.get('FETCH_SIZE'), 'write_size_kb': roll.get('WRITE_SIZE'),
+    t = {'kernel': kern, 'workload': workload, 'fetch_size_kb': roll.get('FETCH_SIZE'), 'write_size_kb': roll.get('WRITE_SIZE'),
          'hbm_bytes_per_launch': (2 * roll.get('FETCH_SIZE', 0.0) + roll.get('WRITE_SIZE', 0.0)) * 1024,
          'correction': '2*FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts 128-B requests at 64 B)',
          'l2_hit_rate': hit / (hit + miss) if hit + miss else None,
          'sq_valu_mfma_busy_cycles_per_launch': roll.get('SQ_VALU_MFMA_BUSY_CYCLES'),
-         'source': 'scripts/collect_profiles.sh (rocprofv3 --pmc, separate passes)'}
+         'source': 'rocprofv3 --pmc, separate passes of `%s`' % cmd}
     json.dump(t, open(os.path.join(out, 'traffic.json'), 'w'), indent=1)
     print(json.dumps(t))

@@ -8,6 +8,8 @@ from ethz_safe_learning_amd import CemPlanner, PlannerConfig, synthetic
 
 CHUNKS = int(os.environ.get('CEM_SWEEP_CHUNKS', '0'))      # 0 = the library's choice; 1..4 forces rows/16 per tile (diagnostic)
 ONLY = os.environ.get('CEM_SWEEP_ONLY', '')
+NOGRAPH = bool(os.environ.get('CEM_SWEEP_NOGRAPH'))          # counter passes: every launch its own dispatch, and only a few plans
+
 CFG = [('B1', 60, 2, 5, 500, 25), ('B2', 60, 2, 5, 2000, 30), ('B3', 60, 2, 16, 8192, 30), ('B4', 100, 12, 8, 4096, 50),
        ('B5/8 (one rank of 8)', 60, 2, 5, 8192, 30)]
 out = []
@@ -16,11 +18,11 @@ for name, O, A, K, N, H in CFG:
         continue
     pb = synthetic.problem(O, A, K)
     cfg = PlannerConfig(obs_dim=O, act_dim=A, ensemble_size=K, particles=K, n_samples=N, horizon=H, n_elite=N // 10, iterations=5,
-                        scorer=pb['scorer'], act_low=pb['low'], act_high=pb['high'], noise_stddev=1e-3, use_graph=True, chunks_per_tile=CHUNKS)
+                        scorer=pb['scorer'], act_low=pb['low'], act_high=pb['high'], noise_stddev=1e-3, use_graph=not NOGRAPH, chunks_per_tile=CHUNKS)
     pl = CemPlanner(cfg); pl.set_weights(pb['weights']); pl.set_normaliser(pb['inputs_min'], pb['inputs_max'])
-    for i in range(3):
+    for i in range(1 if NOGRAPH else 3):
         pl.plan(pb['state'], seed=1, call=i)
-    n = 20 if N <= 2000 else 5
+    n = 2 if NOGRAPH else (20 if N <= 2000 else 5)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(n):
         pl.plan(pb['state'], seed=1, call=10 + i)
