@@ -137,7 +137,20 @@ def main():
     # CEM_BENCH_PYTHON_EXCHANGE=1 keeps the older host-stepped form (torch.distributed all_gather between ctypes calls).
     native = distributed and os.environ.get('CEM_BENCH_PYTHON_EXCHANGE') != '1'
     if native:
-        pl.comm_init()
+        # every rank must end up on the same path: agree on whether the library's communicator came up everywhere, and fall back
+        # to the host-stepped exchange (torch.distributed all_gather between the library calls) on all ranks if it did not
+        try:
+            pl.comm_init()
+            ok = 1
+        except Exception as e:                        # e.g. librccl not loadable from the library, ncclCommInitRank refused
+            sys.stderr.write('rank %d: native RCCL exchange unavailable (%s); using the host-stepped exchange\n' % (rank, e))
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if ok:
+                pl.comm_destroy()
+            native = False
     drv = ShardedCemDriver(pl, I, world_size=G, always_exchange=distributed)
 
     def one_plan(i):
