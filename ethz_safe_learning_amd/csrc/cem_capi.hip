@@ -428,6 +428,7 @@ const char *cem_status_string(int s)
     case CEM_ERR_NO_WEIGHTS: return "set_weights has not been called";
     case CEM_ERR_STATE: return "stepwise plan calls out of order, or a standalone call while a plan is in flight";
     case CEM_ERR_COMM: return "RCCL: library not found or a collective call failed (see cem_last_hip_error for the ncclResult_t)";
+    case CEM_ERR_DEVICE: return "a kernel could not finish its work (floating rollout segment starved of its work-queue entry): result not valid";
     default: return "unknown status";
     }
 }
@@ -845,16 +846,17 @@ void stage_ctrl(cem_planner *h, const float *state, uint64_t seed, uint64_t call
 {
     CtrlBlock *c = h->h_ctrl;
     c->seed_lo = (uint32_t)seed; c->seed_hi = (uint32_t)(seed >> 32); c->call_lo = (uint32_t)call; c->call_hi = (uint32_t)(call >> 32);
-    c->done = 0; c->iters = 0; c->best_score = -std::numeric_limits<float>::infinity();
+    c->done = 0; c->iters = 0; c->fault = 0; c->best_score = -std::numeric_limits<float>::infinity();
     for (int f = 0; f < CEM_U; ++f) c->state[f] = f < h->d.O ? state[f] : 0.f;
     for (int a = 0; a < 32; ++a) c->best[a] = 0.f;
 }
 
-void read_result(cem_planner *h, float *action_out, float *best_score_out, int32_t *iters_out)
+int read_result(cem_planner *h, float *action_out, float *best_score_out, int32_t *iters_out)
 {
     if (action_out) std::memcpy(action_out, h->h_result, h->d.A * 4);
     if (best_score_out) *best_score_out = h->h_result[32];
     if (iters_out) *iters_out = reinterpret_cast<int32_t *>(h->h_result)[33];
+    return reinterpret_cast<int32_t *>(h->h_result)[35] ? CEM_ERR_DEVICE : CEM_OK;     // a kernel gave up (CtrlBlock::fault)
 }
 
 }  // namespace
@@ -898,8 +900,7 @@ int cem_plan_end(cem_planner_t *h, const float *eps_out_host, float *action_out,
     int st = enqueue_end(h, eps_out_host != nullptr); if (st) return st;
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->timing) collect_timing(h);
-    read_result(h, action_out, best_score_out, iters_out);
-    return CEM_OK;
+    return read_result(h, action_out, best_score_out, iters_out);
 }
 
 int cem_planner_plan(cem_planner_t *h, const float *state, uint64_t seed, uint64_t call, const float *eps_act_dev,
@@ -940,8 +941,7 @@ int cem_planner_plan(cem_planner_t *h, const float *state, uint64_t seed, uint64
         if (h->graph_ready) {
             HIPCHK(hipGraphLaunch(h->gexec, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
-            read_result(h, action_out, best_score_out, iters_out);
-            return CEM_OK;
+            return read_result(h, action_out, best_score_out, iters_out);
         }
     }
     int st = cem_plan_begin(h, state, seed, call, eps_act_dev, eps_model_dev); if (st) return st;

@@ -45,7 +45,7 @@ struct CtrlBlock {
     int32_t done;            // early stop reached (cem_mpc.py:66-67)
     int32_t iters;           // iterations run
     float best_score;        // best_so_far_score (cem_mpc.py:42)
-    int32_t pad;
+    int32_t fault;           // set by a kernel that had to give up (cem_rollout_seg_kernel's bounded spin); reported as CEM_ERR_DEVICE
     float state[CEM_U];      // the observation (cem_mpc.py:32)
     float best[32];          // best_so_far (cem_mpc.py:41)
 };
@@ -673,7 +673,8 @@ __global__ __launch_bounds__(256) void cem_rollout_seg_kernel(const RolloutParam
             uint32_t spins = 0, v;
             while ((v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && ++spins < CEM_SEG_SPIN_LIMIT)
                 __builtin_amdgcn_s_sleep(16);
-            item = v ? v - 1u : 0xffffffffu;               // never filled within the limit: give up rather than hang the device
+            item = v ? v - 1u : 0xffffffffu;               // never filled within the limit: give up rather than hang the device ...
+            if (!v) atomicOr(const_cast<int32_t *>(&p.ctrl->fault), 1);   // ... and say so: the host returns CEM_ERR_DEVICE for this plan
         }
         item_s = item;
     }
@@ -703,7 +704,7 @@ __global__ void cem_init_kernel(const InitParams p)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < p.HA) { p.musig[i] = p.mu0[i % p.A]; p.musig[p.HA + i] = p.sigma0[i % p.A]; }   // cem_mpc.py:39-40
     if (i < 32) p.ctrl->best[i] = 0.f;                                                         // cem_mpc.py:41
-    if (i == 0) { p.ctrl->best_score = -__builtin_inff(); p.ctrl->done = 0; p.ctrl->iters = 0; }
+    if (i == 0) { p.ctrl->best_score = -__builtin_inff(); p.ctrl->done = 0; p.ctrl->iters = 0; p.ctrl->fault = 0; }
 }
 
 struct SampleParams {
@@ -1500,6 +1501,7 @@ __global__ void cem_final_kernel(const FinalParams p)
         p.result[32] = p.ctrl->best_score;
         reinterpret_cast<int32_t *>(p.result)[33] = p.ctrl->iters;
         reinterpret_cast<int32_t *>(p.result)[34] = p.ctrl->done;
+        reinterpret_cast<int32_t *>(p.result)[35] = p.ctrl->fault;
     }
 }
 

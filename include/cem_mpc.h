@@ -42,7 +42,9 @@ enum cem_status {
     CEM_ERR_HIP = 5,             /* a HIP runtime call failed; cem_last_hip_error() has the code */
     CEM_ERR_NO_WEIGHTS = 6,      /* plan() before set_weights() */
     CEM_ERR_STATE = 7,           /* stepwise calls out of order, or a call that would clobber the state of a plan in flight */
-    CEM_ERR_COMM = 8             /* librccl could not be opened, or an RCCL call failed (cem_last_hip_error() holds the ncclResult_t) */
+    CEM_ERR_COMM = 8,            /* librccl could not be opened, or an RCCL call failed (cem_last_hip_error() holds the ncclResult_t) */
+    CEM_ERR_DEVICE = 9           /* a kernel reported that it could not finish its work (a floating rollout segment never received its
+                                    work-queue entry within the spin bound): the plan's result is not valid */
 };
 
 enum cem_variant { CEM_VARIANT_CEM = 0 /* CemMpc */, CEM_VARIANT_SAFE = 1 /* SafeCemMpc */ };

@@ -68,6 +68,13 @@ def test_validation_errors(built_lib, kw, status):
     assert built_lib.cem_status_string(status)
 
 
+def test_every_status_code_has_its_own_message(built_lib):
+    # include/cem_mpc.h: CEM_OK .. CEM_ERR_DEVICE (9: a kernel gave up — the floating-segment queue's bounded spin)
+    msgs = [built_lib.cem_status_string(i).decode() for i in range(10)]
+    assert all(msgs) and len(set(msgs)) == 10
+    assert 'kernel' in msgs[9] and 'RCCL' in msgs[8]
+
+
 def test_goal_threshold_crosses_the_abi_rounded_once():
     # fl32(0.3 * 0.8) evaluated in double = 0.23999999..., not fl32(0.3) * 0.8 = 0.24000001 (safety_gym.py:116)
     cc = to_c_config(_cfg())
