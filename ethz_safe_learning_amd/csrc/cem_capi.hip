@@ -1151,6 +1151,7 @@ struct cem_trainer {
     size_t nat, scratch_pm;
     size_t oW, oM, oV, oG, oS, oL, oP, oT, total;
     bool tile_kernel;
+    float *eval_part; size_t eval_part_floats;     // per-chunk loss partials of a one-launch validation pass (grown on demand, kept)
 };
 
 namespace {
@@ -1191,7 +1192,7 @@ hipError_t tile_kernel_lds(size_t lds)
 void launch_train_step(const cem_trainer *t, const TrainParams &p)
 {
     const size_t lds = (size_t)(t->cfg.n_layers + 5) * CEM_TT_NB * CEM_TT_BLK;
-    const dim3 grid(t->cfg.ensemble_size * CEM_TPARTS);
+    const dim3 grid(t->cfg.ensemble_size * CEM_TPARTS, t->tile_kernel ? (p.Bt + p.chunk - 1) / p.chunk : 1);
     if (!t->tile_kernel) { hipLaunchKernelGGL(cem_train_step_kernel, grid, dim3(CEM_TNT), 0, t->stream, p); return; }
     switch (t->cfg.n_layers) {
 #define CEM_CASE(LL) case LL: hipLaunchKernelGGL(cem_train_tile_kernel<LL>, grid, dim3(64 * CEM_TT_WAVES), lds, t->stream, p); break;
@@ -1258,6 +1259,7 @@ int cem_trainer_destroy(cem_trainer_t *t)
 {
     if (!t) return CEM_ERR_INVALID_ARG;
     if (t->own_stream) hipStreamDestroy(t->stream);
+    if (t->eval_part) hipFree(t->eval_part);
     delete t;
     return CEM_OK;
 }
@@ -1290,7 +1292,7 @@ int cem_trainer_step(cem_trainer_t *t, const float *x_dev, const float *y_dev, c
     if (!t || !x_dev || !y_dev || !loss_dev || bt < 1 || bt > t->cfg.batch_size || offset < 0) return CEM_ERR_INVALID_ARG;
     if (perm_dev && offset + bt > nperm) return CEM_ERR_INVALID_ARG;
     TrainParams p; fill_train_params(t, p);
-    p.x = x_dev; p.y = y_dev; p.perm = perm_dev; p.nperm = nperm; p.offset = offset; p.Bt = bt; p.lr_t = lr_t; p.loss_out = loss_dev; p.train = 1;
+    p.x = x_dev; p.y = y_dev; p.perm = perm_dev; p.nperm = nperm; p.offset = offset; p.Bt = bt; p.chunk = bt; p.lr_t = lr_t; p.loss_out = loss_dev; p.train = 1;
     launch_train_step(t, p);
     const size_t n4 = (size_t)p.E * p.nat / 4;
     const unsigned adam_grid = (unsigned)std::min<size_t>(std::max<size_t>((n4 + 255) / 256, 1), 2048);
@@ -1314,19 +1316,40 @@ int cem_trainer_eval(cem_trainer_t *t, const float *x_dev, const float *y_dev, i
 {
     if (!t || !x_dev || !y_dev || !loss_out || n < 1) return CEM_ERR_INVALID_ARG;
     const int E = t->cfg.ensemble_size;
-    std::vector<float> sums((size_t)E * 2), part((size_t)E * CEM_TPARTS * 2);
+    std::vector<float> sums((size_t)E * 2);
     std::fill(sums.begin(), sums.end(), 0.f);
     TrainParams p; fill_train_params(t, p);
     p.x = x_dev; p.y = y_dev; p.perm = nullptr; p.loss_out = (float *)(t->ws + t->oL); p.train = 0;
-    for (int off = 0; off < n; off += t->cfg.batch_size) {
-        p.offset = off; p.Bt = std::min(t->cfg.batch_size, n - off);
+    const int B = t->cfg.batch_size, nchunks = (n + B - 1) / B;
+    const size_t per_chunk = (size_t)E * CEM_TPARTS * 2;
+    std::vector<float> part(per_chunk * (t->tile_kernel ? nchunks : 1));
+    // the sums are added on the host in the same order either way: chunk by chunk, member by member, part by part
+    auto add_chunk = [&](const float *pc, int rows) {
+        const int nparts = (rows + CEM_TROWS - 1) / CEM_TROWS;
+        for (int m = 0; m < E; ++m)
+            for (int q = 0; q < nparts; ++q) { sums[2 * m] += pc[((size_t)m * CEM_TPARTS + q) * 2]; sums[2 * m + 1] += pc[((size_t)m * CEM_TPARTS + q) * 2 + 1]; }
+    };
+    if (t->tile_kernel) {
+        // ONE launch for the whole set: grid.y walks the 64-row chunks, each writing its own loss partials
+        if (t->eval_part_floats < part.size()) {
+            if (t->eval_part) { HIPCHK(hipStreamSynchronize(t->stream)); HIPCHK(hipFree(t->eval_part)); t->eval_part = nullptr; t->eval_part_floats = 0; }
+            HIPCHK(hipMalloc((void **)&t->eval_part, part.size() * 4)); t->eval_part_floats = part.size();
+        }
+        p.offset = 0; p.Bt = n; p.chunk = B; p.loss_part = t->eval_part;
         launch_train_step(t, p);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(part.data(), t->ws + t->oP, part.size() * 4, hipMemcpyDeviceToHost, t->stream));
+        HIPCHK(hipMemcpyAsync(part.data(), t->eval_part, part.size() * 4, hipMemcpyDeviceToHost, t->stream));
         HIPCHK(hipStreamSynchronize(t->stream));
-        const int nparts = (p.Bt + CEM_TROWS - 1) / CEM_TROWS;
-        for (int m = 0; m < E; ++m)
-            for (int q = 0; q < nparts; ++q) { sums[2 * m] += part[((size_t)m * CEM_TPARTS + q) * 2]; sums[2 * m + 1] += part[((size_t)m * CEM_TPARTS + q) * 2 + 1]; }
+        for (int ch = 0; ch < nchunks; ++ch) add_chunk(part.data() + (size_t)ch * per_chunk, std::min(B, n - ch * B));
+    } else {
+        for (int off = 0; off < n; off += B) {
+            p.offset = off; p.Bt = std::min(B, n - off); p.chunk = p.Bt;
+            launch_train_step(t, p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(part.data(), t->ws + t->oP, part.size() * 4, hipMemcpyDeviceToHost, t->stream));
+            HIPCHK(hipStreamSynchronize(t->stream));
+            add_chunk(part.data(), p.Bt);
+        }
     }
     const double cnt = (double)n * t->cfg.outputs_dim;
     double total = 0;

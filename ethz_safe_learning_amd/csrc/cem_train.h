@@ -27,7 +27,8 @@ struct TrainParams {
     float *scratch;              // [E * CEM_TPARTS][scratch_per_member]
     const float *x, *y;          // [n][D] scaled inputs, [n][O] targets (next_obs - obs)
     const int32_t *perm;         // [E][nperm] bootstrap shuffles (mlp_ensemble.py:172-173) or nullptr (rows offset.. directly)
-    int32_t nperm, offset, Bt;
+    int32_t nperm, offset, Bt;   // Bt rows from `offset` on; the tile kernel takes them in chunks of `chunk` rows along blockIdx.y (training: one
+    int32_t chunk;               // chunk = the minibatch; validation: every 64-row slice of the set in ONE launch, loss_part per chunk)
     int32_t D, O, U, L, E;
     uint32_t nat, scratch_per_member, gpart;
     float lr_t, beta1, beta2, eps, clip;

@@ -161,8 +161,11 @@ __global__ __launch_bounds__(64 * CEM_TT_WAVES) void cem_train_tile_kernel(const
     __shared__ int32_t rows_s[CEM_TROWS];
     const int m = blockIdx.x / CEM_TPARTS, part = blockIdx.x % CEM_TPARTS, tid = threadIdx.x;
     const int D = p.D, O = p.O, U = p.U;
+    // rows of this workgroup: chunk blockIdx.y of the launch (training launches have one chunk = the minibatch), part `part` of it
+    const int chunk0 = (int)blockIdx.y * p.chunk;
+    const int Bt = p.Bt - chunk0 < p.chunk ? p.Bt - chunk0 : p.chunk;
     const int row0 = part * CEM_TROWS;
-    const int cnt = p.Bt - row0 < CEM_TROWS ? p.Bt - row0 : CEM_TROWS;
+    const int cnt = Bt - row0 < CEM_TROWS ? Bt - row0 : CEM_TROWS;
     if (cnt <= 0) return;                          // a short minibatch: the Adam kernel only adds the parts that exist
     TtCtx c; c.lane = tid & 63; c.q = c.lane >> 4; c.j = c.lane & 15; c.w = __builtin_amdgcn_readfirstlane(tid >> 6); c.cnt = cnt;
     const gcptr W = (gcptr)(p.W + (size_t)m * p.nat);
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(64 * CEM_TT_WAVES) void cem_train_tile_kernel(const
 
     if (tid < CEM_TROWS) {
         const int rr = tid < cnt ? tid : cnt - 1;                  // rows past the end repeat the last one; their gradients are masked to zero
-        rows_s[tid] = p.perm ? p.perm[(size_t)m * p.nperm + p.offset + row0 + rr] : p.offset + row0 + rr;
+        rows_s[tid] = p.perm ? p.perm[(size_t)m * p.nperm + p.offset + chunk0 + row0 + rr] : p.offset + chunk0 + row0 + rr;
     }
     __syncthreads();
     const int myrow = rows_s[c.j];
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(64 * CEM_TT_WAVES) void cem_train_tile_kernel(const
 
     // ---- heads (mlp_ensemble.py:33-34) + negative_log_likelihood (:64-67) and its gradients: stage L ----------------------------
     float s_log = 0.f, s_sq = 0.f;
-    const float ninv = 1.0f / ((float)p.Bt * (float)O * (float)p.E);       // the mean runs over the WHOLE minibatch
+    const float ninv = 1.0f / ((float)Bt * (float)O * (float)p.E);         // the mean runs over the WHOLE minibatch
     if (p.train) load_bwd(wb[(L + 1) & 1], W + oWmu, U * O, O);            // stage L + 1: the W_mu part of dh_L
     if (ownO) {                                                            // wave-uniform
         f4 acc[2];
@@ -284,8 +287,8 @@ __global__ __launch_bounds__(64 * CEM_TT_WAVES) void cem_train_tile_kernel(const
         float a = red[0][0], b = red[1][0];
 #pragma unroll
         for (int w = 1; w < CEM_TT_WAVES; ++w) { a += red[0][w]; b += red[1][w]; }
-        p.loss_part[((size_t)m * CEM_TPARTS + part) * 2] = a;
-        p.loss_part[((size_t)m * CEM_TPARTS + part) * 2 + 1] = b;
+        float *lp = p.loss_part + (((size_t)blockIdx.y * p.E + m) * CEM_TPARTS + part) * 2;
+        lp[0] = a; lp[1] = b;
     }
     if (!p.train) return;
 
