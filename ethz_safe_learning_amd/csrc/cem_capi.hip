@@ -1335,9 +1335,14 @@ int cem_trainer_eval(cem_trainer_t *t, const float *x_dev, const float *y_dev, i
             if (t->eval_part) { HIPCHK(hipStreamSynchronize(t->stream)); HIPCHK(hipFree(t->eval_part)); t->eval_part = nullptr; t->eval_part_floats = 0; }
             HIPCHK(hipMalloc((void **)&t->eval_part, part.size() * 4)); t->eval_part_floats = part.size();
         }
-        p.offset = 0; p.Bt = n; p.chunk = B; p.loss_part = t->eval_part;
-        launch_train_step(t, p);
-        HIPCHK(hipGetLastError());
+        p.chunk = B;
+        const int kMaxChunks = 32768;                   // grid.y is limited to 65535: very large sets go in several launches
+        for (int c0 = 0; c0 < nchunks; c0 += kMaxChunks) {
+            const int nc = std::min(kMaxChunks, nchunks - c0);
+            p.offset = c0 * B; p.Bt = std::min(n - c0 * B, nc * B); p.loss_part = t->eval_part + (size_t)c0 * per_chunk;
+            launch_train_step(t, p);
+            HIPCHK(hipGetLastError());
+        }
         HIPCHK(hipMemcpyAsync(part.data(), t->eval_part, part.size() * 4, hipMemcpyDeviceToHost, t->stream));
         HIPCHK(hipStreamSynchronize(t->stream));
         for (int ch = 0; ch < nchunks; ++ch) add_chunk(part.data() + (size_t)ch * per_chunk, std::min(B, n - ch * B));

@@ -143,3 +143,29 @@ def test_fit_small_dataset_uses_every_epochs_own_shuffle():
     ref = np.array(ref)
     np.testing.assert_allclose(losses[:12], ref[:12], rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(losses, ref, rtol=3e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize('kernel', ['tile', 'gemm'])
+def test_validation_loss_over_many_chunks(kernel, monkeypatch):
+    """validation_step over a set of 3001 rows (47 chunks of 64, the last one ragged): the tile kernel takes it as ONE launch
+    (grid.y walks the chunks), the GEMM kernel chunk by chunk; both against the fp64 oracle."""
+    import torch
+    from ethz_safe_learning_amd.trainer import CemTrainer
+    if kernel == 'gemm':
+        monkeypatch.setenv('CEM_TRAIN_GEMM_KERNEL', '1')
+    else:
+        monkeypatch.delenv('CEM_TRAIN_GEMM_KERNEL', raising=False)
+    E, D, O, L, units = 3, 30, 28, 2, 48
+    pb = hp.make_problem(O, D - O, E, L, seed=77, bias_noise=0.05, head_scale=0.3, var_bias=-2.0, units=units)
+    rng = np.random.default_rng(5)
+    n = 3001
+    X = rng.normal(0, 0.5, (n, D)).astype(np.float32)
+    Y = (0.1 * X[:, :O] + 0.05 * rng.normal(0, 1, (n, O))).astype(np.float32)
+    tr = CemTrainer(D, O, units, L, E, batch_size=64)
+    tr.set_state(pb['weights'])
+    ref = o.validation_loss(o.cast_weights(pb['weights'], np.float64), X.astype(np.float64), Y.astype(np.float64))
+    for rows in (n, 64, 65, 1):
+        got = tr.validation_loss(torch.from_numpy(X[:rows]).cuda(), torch.from_numpy(Y[:rows]).cuda())
+        want = ref if rows == n else o.validation_loss(o.cast_weights(pb['weights'], np.float64), X[:rows].astype(np.float64), Y[:rows].astype(np.float64))
+        assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (rows, got, want)
+    tr.close()
