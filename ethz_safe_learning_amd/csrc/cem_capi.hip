@@ -122,16 +122,16 @@ void pack_member(const Dims &d, const float *nat, float *out)
         }
         for (int l = 1; l < d.L; ++l)
             for (int P = 0; P < CEM_NG; ++P) {
-                const int F = cem_perm_hidden(w, P);
-                emit(nat + no.W[l], d.U, d.U, d.U, F, 0, 2 * w); emit(nat + no.W[l], d.U, d.U, d.U, F, 1, 2 * w + 1);
+                const int F = cem_perm_hidden(w, P), Fb = cem_perm_hidden(w, P < 2 ? (P ^ 1) : P);   // second accumulator: own blocks swapped
+                emit(nat + no.W[l], d.U, d.U, d.U, F, 0, 2 * w); emit(nat + no.W[l], d.U, d.U, d.U, Fb, 1, 2 * w + 1);
                 dst += 512;
             }
         for (int i = 0; i < d.NFW; ++i) {
             const int Fo = w + 4 * i;
             if (Fo >= d.KB_obs) continue;
             for (int P = 0; P < CEM_NG; ++P) {                    // heads: g=0 mu, g=1 var of obs block Fo
-                const int F = cem_perm_hidden(w, P);
-                emit(nat + no.Wmu, d.U, d.O, d.O, F, 0, Fo); emit(nat + no.Wvar, d.U, d.O, d.O, F, 1, Fo);
+                const int F = cem_perm_hidden(w, P), Fb = cem_perm_hidden(w, P < 2 ? (P ^ 1) : P);
+                emit(nat + no.Wmu, d.U, d.O, d.O, F, 0, Fo); emit(nat + no.Wvar, d.U, d.O, d.O, Fb, 1, Fo);
                 dst += 512;
             }
         }

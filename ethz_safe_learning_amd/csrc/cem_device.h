@@ -259,12 +259,17 @@ __device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], f
             }
         }
         const AGroup g = wq.slot[P & 3];
+        // Canonical k order of an OUTPUT block b of a hidden / heads stage: block b itself, block b ^ 1, then the rest ascending.
+        // The wave's two accumulators are blocks 2w and 2w + 1, so the second one visits the wave's own two input blocks swapped
+        // (its weights are packed to match).  Every output block thus starts on the input block of the same index — which is what
+        // lets the 8-wave form of this kernel (one output block per wave, cem_rollout_w8_kernel) produce bit-identical sums.
+        const int Pb = (!L0IN && P < 2) ? (P ^ 1) : P;            // (P is a compile-time constant once the loop is unrolled)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
             for (int c = 0; c < RC; ++c) {
                 acc0[c] = CEM_MFMA(g.a[r], hB[P][c][r], acc0[c]);
-                acc1[c] = CEM_MFMA(g.b[r], hB[P][c][r], acc1[c]);
+                acc1[c] = CEM_MFMA(g.b[r], hB[Pb][c][r], acc1[c]);
             }
         }
     }

@@ -62,11 +62,13 @@ class TileEmulator:
             acc1 = np.zeros((rc, 64, 4))
             for P in range(kf):
                 F = perm_l0(w, kf // 4, P) if l0 else perm_hidden(w, P)
+                # the second accumulator of a hidden stage visits the wave's own two input blocks swapped (cem_mfma_stage)
+                Fb = F if l0 else perm_hidden(w, P ^ 1 if P < 2 else P)
                 g = self.pop(w)
                 for r in range(4):
                     for c in range(rc):
                         acc0[c] = mfma_16x16x4(g[0][:, r], X[c, F, :, r], acc0[c])
-                        acc1[c] = mfma_16x16x4(g[1][:, r], X[c, F, :, r], acc1[c])
+                        acc1[c] = mfma_16x16x4(g[1][:, r], X[c, Fb, :, r], acc1[c])
             outs.append((acc0, acc1))
         return outs
 
@@ -120,11 +122,12 @@ class TileEmulator:
                     acc_v = np.zeros((rc, 64, 4))
                     for P in range(8):
                         F = perm_hidden(w, P)
+                        Fb = perm_hidden(w, P ^ 1 if P < 2 else P)
                         g = self.pop(w)
                         for r in range(4):
                             for c in range(rc):
                                 acc_m[c] = mfma_16x16x4(g[0][:, r], X[c, F, :, r], acc_m[c])
-                                acc_v[c] = mfma_16x16x4(g[1][:, r], X[c, F, :, r], acc_v[c])
+                                acc_v[c] = mfma_16x16x4(g[1][:, r], X[c, Fb, :, r], acc_v[c])
                     per_wave[w].append((Fo, acc_m, acc_v))
         for w in range(4):
             for Fo, acc_m, acc_v in per_wave[w]:
