@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-CEM_ABI_VERSION = 3
+CEM_ABI_VERSION = 2
 CEM_MAX_ACT = 32
 CEM_MAX_COST_KINDS = 4
 CEM_COMM_ID_BYTES = 128
@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get('CEM_MPC_LIB') or os.path.join(_HERE, 'lib', 'libcem_m
 
 EXPORTED_SYMBOLS = [
     'cem_abi_version', 'cem_status_string', 'cem_last_hip_error', 'cem_weight_blob_floats',
-    'cem_packed_weight_floats', 'cem_workspace_bytes', 'cem_pack_weights_host', 'cem_plan_tiles_host', 'cem_plan_segments_host', 'cem_plan_waves_host', 'cem_rollout_residency',
+    'cem_packed_weight_floats', 'cem_workspace_bytes', 'cem_pack_weights_host', 'cem_plan_tiles_host', 'cem_plan_segments_host', 'cem_rollout_residency',
     'cem_planner_create', 'cem_planner_destroy', 'cem_planner_layout', 'cem_planner_set_weights',
     'cem_planner_set_normaliser', 'cem_planner_plan', 'cem_plan_begin', 'cem_plan_rollout', 'cem_plan_select',
     'cem_plan_end', 'cem_comm_unique_id', 'cem_planner_comm_init', 'cem_planner_comm_destroy', 'cem_plan_exchange', 'cem_planner_graph_status', 'cem_unfold_sequences', 'cem_compute_objective', 'cem_scorer_reward', 'cem_scorer_cost', 'cem_fill_noise', 'cem_planner_set_timing', 'cem_planner_last_timing',
@@ -52,7 +52,7 @@ class CemConfig(C.Structure):
         ('act_mu0', C.c_float * CEM_MAX_ACT), ('act_sigma0', C.c_float * CEM_MAX_ACT),
         ('scorer', CemScorer),
         ('world_size', C.c_int32), ('rank', C.c_int32), ('chunks_per_tile', C.c_int32), ('use_graph', C.c_int32),
-        ('select_mode', C.c_int32), ('rollout_segments', C.c_int32), ('rollout_waves', C.c_int32),
+        ('select_mode', C.c_int32), ('rollout_segments', C.c_int32),
     ]
 
 
@@ -99,7 +99,6 @@ def load():
     lib.cem_pack_weights_host.argtypes = [cfgp, vp, vp]
     lib.cem_plan_tiles_host.argtypes = [cfgp, i32p, i32p, vp, C.c_int32]
     lib.cem_plan_segments_host.argtypes = [cfgp, i32p, i32p]
-    lib.cem_plan_waves_host.argtypes = [cfgp, i32p]
     lib.cem_rollout_residency.argtypes = [C.c_int32, C.c_int32, i32p, i32p]
     lib.cem_planner_create.argtypes = [cfgp, vp, C.c_size_t, vp, C.POINTER(vp)]
     lib.cem_planner_destroy.argtypes = [vp]

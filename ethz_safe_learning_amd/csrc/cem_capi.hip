@@ -3,7 +3,6 @@
 #include "cem_device.h"
 #include "cem_train.h"
 #include "cem_train_tile.h"
-#include "cem_rollout_w8.h"
 #include "../../include/cem_mpc.h"
 
 #include <dlfcn.h>
@@ -63,7 +62,6 @@ int validate(const cem_config_t *c)
     if (c->chunks_per_tile < 0 || c->chunks_per_tile > 4) return CEM_ERR_INVALID_ARG;
     if (c->rollout_segments < 0 || c->rollout_segments > 64) return CEM_ERR_INVALID_ARG;
     if (c->select_mode < 0 || c->select_mode > 2) return CEM_ERR_INVALID_ARG;
-    if (c->rollout_waves != 0 && c->rollout_waves != 4 && c->rollout_waves != 8) return CEM_ERR_INVALID_ARG;
     if ((long long)c->particles * c->n_samples > (1ll << 30)) return CEM_ERR_UNSUPPORTED;
     return CEM_OK;
 }
@@ -287,7 +285,7 @@ struct Layout {
         ms_hist, ms_sel, ms_counts, ms_best_sc, ms_best_ix, ms_part, ms_colmean, total;
 };
 
-struct Plan { int rc, n_tiles, n_seg, seg_len, n_pinned, waves; };
+struct Plan { int rc, n_tiles, n_seg, seg_len, n_pinned; };
 
 // tile size, tile count and horizon segments of a configuration: one function, so workspace_bytes / create / the host helpers agree
 Plan make_plan(const cem_config_t *c, const Dims &d)
@@ -302,10 +300,6 @@ Plan make_plan(const cem_config_t *c, const Dims &d)
     // tiles every CU gets the same number of stay whole ("pinned"); only the remainder floats in segments
     pl.n_pinned = pl.n_seg > 1 ? (pl.n_tiles / kNumCUs) * kNumCUs : pl.n_tiles;
     if (c->rollout_segments > 1 && pl.n_pinned == pl.n_tiles && pl.n_seg > 1) pl.n_pinned = 0;   // an explicit request floats everything
-    // the 8-wave workgroup (cem_rollout_w8.h): one-chunk tiles, one input block per wave, unsegmented; by itself only where a CU
-    // gets at most one tile (a second resident workgroup hides a 4-wave tile's bubbles just as well)
-    const bool w8_able = pl.rc == 1 && d.NFW == 1 && pl.n_seg == 1;
-    pl.waves = (c->rollout_waves == 8 || (c->rollout_waves == 0 && pl.n_tiles <= kNumCUs)) && w8_able ? 8 : 4;
     return pl;
 }
 
@@ -395,7 +389,6 @@ struct cem_planner {
     bool own_stream;
     int rc;
     int n_tiles;
-    int waves;                              // 4, or 8: cem_rollout_w8_kernel (Plan::waves)
     int n_seg, seg_len, n_pinned;           // horizon segments of the floating tiles (1 = one workgroup per tile), tiles that stay whole
     bool have_weights;
     bool in_plan;
@@ -485,16 +478,6 @@ int cem_plan_tiles_host(const cem_config_t *cfg, int32_t *rc_out, int32_t *n_til
     return CEM_OK;
 }
 
-int cem_plan_waves_host(const cem_config_t *cfg, int32_t *waves_out)
-{
-    int st = validate(cfg); if (st) return st;
-    const Dims d = make_dims(cfg);
-    const Plan pl = make_plan(cfg, d);
-    if (cfg->rollout_waves == 8 && pl.waves != 8) return CEM_ERR_UNSUPPORTED;     // asked for, but the shape does not take it
-    if (waves_out) *waves_out = pl.waves;
-    return CEM_OK;
-}
-
 int cem_plan_segments_host(const cem_config_t *cfg, int32_t *segments_out, int32_t *steps_per_segment_out)
 {
     int st = validate(cfg); if (st) return st;
@@ -524,7 +507,6 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
 {
     int st = validate(cfg); if (st) return st;
     if (!workspace || !out) return CEM_ERR_INVALID_ARG;
-    if (cfg->rollout_waves == 8 && make_plan(cfg, make_dims(cfg)).waves != 8) return CEM_ERR_UNSUPPORTED;   // this shape does not take the 8-wave form
     cem_planner *h = new (std::nothrow) cem_planner();
     if (!h) return CEM_ERR_INVALID_ARG;
     h->cfg = *cfg; h->d = make_dims(cfg);
@@ -535,7 +517,7 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { g_last_hip = (int)hipGetLastError(); delete h; return CEM_ERR_HIP; }
         h->own_stream = true;
     }
-    { const Plan pl = make_plan(cfg, h->d); h->rc = pl.rc; h->n_seg = pl.n_seg; h->seg_len = pl.seg_len; h->n_pinned = pl.n_pinned; h->waves = pl.waves; }
+    { const Plan pl = make_plan(cfg, h->d); h->rc = pl.rc; h->n_seg = pl.n_seg; h->seg_len = pl.seg_len; h->n_pinned = pl.n_pinned; }
     h->have_weights = false; h->in_plan = false; h->eps_act = h->eps_model = nullptr;
     h->timing = false; h->roll_ms = h->sel_ms = 0.f; h->roll_n = 0;
     h->graph = nullptr; h->gexec = nullptr; h->graph_ready = false;
@@ -773,9 +755,6 @@ int enqueue_rollout(cem_planner *h, int it)
         rp.seg_len = h->seg_len; rp.n_seg = h->n_seg; rp.n_tiles = h->n_tiles; rp.n_pinned = h->n_pinned;
         // one workgroup per pinned tile, then one per (floating tile, segment) item
         HIPCHK(launch_rollout_seg(h->rc, d.NFW, rp, h->n_pinned + h->n_seg * (h->n_tiles - h->n_pinned), h->stream));
-    } else if (h->waves == 8) {
-        hipLaunchKernelGGL(cem_rollout_w8_kernel, dim3(h->n_tiles), dim3(512), CEM_W8_SMEM, h->stream, rp);
-        HIPCHK(hipGetLastError());
     } else HIPCHK(launch_rollout<0>(h->rc, d.NFW, rp, h->n_tiles, h->stream));
     if (h->timing) hipEventRecord(get_event(h, e0 + 1), h->stream);
 

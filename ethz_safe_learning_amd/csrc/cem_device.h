@@ -261,8 +261,9 @@ __device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], f
         const AGroup g = wq.slot[P & 3];
         // Canonical k order of an OUTPUT block b of a hidden / heads stage: block b itself, block b ^ 1, then the rest ascending.
         // The wave's two accumulators are blocks 2w and 2w + 1, so the second one visits the wave's own two input blocks swapped
-        // (its weights are packed to match).  Every output block thus starts on the input block of the same index — which is what
-        // lets the 8-wave form of this kernel (one output block per wave, cem_rollout_w8_kernel) produce bit-identical sums.
+        // (its weights are packed to match).  Every output block thus starts on the input block of the same index, whichever wave
+        // computes it: a form of the kernel that spreads the output blocks over more waves sums in the same order (the 8-wave
+        // workgroup of commit 0e0e847 was bit-identical to this kernel — and 1.5 % slower at B1, hence not kept).
         const int Pb = (!L0IN && P < 2) ? (P ^ 1) : P;            // (P is a compile-time constant once the loop is unrolled)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

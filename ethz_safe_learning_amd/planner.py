@@ -60,7 +60,6 @@ class PlannerConfig:
     chunks_per_tile: int = 0
     use_graph: bool = False
     rollout_segments: int = 0          # 0 auto, 1 off, n > 1: horizon-segment work queue (cem_mpc.h)
-    rollout_waves: int = 0             # 0 auto, 4, 8: waves per rollout workgroup (cem_mpc.h)
     select_mode: int = 0               # 0 auto, 1 one-workgroup select, 2 multi-workgroup select chain (cem_mpc.h)
 
 
@@ -111,7 +110,6 @@ def to_c_config(cfg: PlannerConfig) -> _capi.CemConfig:
         c.scorer.cost_lo[i], c.scorer.cost_hi[i], c.scorer.cost_size[i] = int(lo), int(hi), float(size)
     c.world_size, c.rank, c.chunks_per_tile, c.use_graph = cfg.world_size, cfg.rank, cfg.chunks_per_tile, int(cfg.use_graph)
     c.rollout_segments = int(cfg.rollout_segments)
-    c.rollout_waves = int(cfg.rollout_waves)
     c.select_mode = int(cfg.select_mode)
     return c
 
@@ -420,12 +418,6 @@ class CemPlanner:
     def tiles(self):
         """(chunks_per_tile, tiles[n,6]) of this handle's plan (host-side logic, no GPU call)."""
         return plan_tiles(self.cfg)
-
-    def waves(self):
-        """waves per rollout workgroup of this configuration: 4, or 8 (cem_rollout_w8_kernel; cem_plan_waves_host)."""
-        w = C.c_int32()
-        _capi.check(self.lib.cem_plan_waves_host(C.byref(self.ccfg), C.byref(w)), 'cem_plan_waves_host')
-        return int(w.value)
 
     def segments(self):
         return plan_segments(self.cfg)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CEM_ABI_VERSION 3
+#define CEM_ABI_VERSION 2
 #define CEM_MAX_ACT 32
 #define CEM_MAX_COST_KINDS 4
 
@@ -104,9 +104,6 @@ typedef struct cem_config {
     int32_t rollout_segments;     /* 0 = auto; 1 = one workgroup per tile for the whole horizon; n > 1 = the rollout launch is a
                                    * work queue of (tile, horizon/n) items drawn by resident workgroups — evens out CU load when the
                                    * tile count is not a multiple of the CU count; results are bit-identical either way */
-    int32_t rollout_waves;        /* 0 = auto; 4 = the 4-wave workgroup per tile; 8 = the 8-wave form (one output block per wave, two waves
-                                   * per SIMD) for launches of at most one one-chunk tile per CU with obs+act <= 64 — elsewhere 8 is
-                                   * CEM_ERR_UNSUPPORTED; results are bit-identical either way */
 } cem_config_t;
 
 /* Byte offsets into the caller's workspace of the arrays a host binding needs
@@ -141,8 +138,6 @@ size_t cem_workspace_bytes(const cem_config_t *cfg);
 int cem_pack_weights_host(const cem_config_t *cfg, const float *blob, float *packed);
 int cem_plan_tiles_host(const cem_config_t *cfg, int32_t *chunks_per_tile_out, int32_t *n_tiles_out,
                         int32_t *tiles_out /* [n_tiles][6]: row_base,cnt,member,act_base,noise_row_base,s0_base */, int32_t max_tiles);
-/* waves per rollout workgroup the configuration runs with (4 or 8; cem_config_t::rollout_waves), as cem_planner_create would choose */
-int cem_plan_waves_host(const cem_config_t *cfg, int32_t *waves_out);
 /* horizon segments the rollout launch of this configuration uses (1 = unsegmented), as cem_planner_create would choose */
 int cem_plan_segments_host(const cem_config_t *cfg, int32_t *segments_out, int32_t *steps_per_segment_out);
 

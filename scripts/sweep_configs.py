@@ -8,7 +8,6 @@ from ethz_safe_learning_amd import CemPlanner, PlannerConfig, synthetic
 
 CHUNKS = int(os.environ.get('CEM_SWEEP_CHUNKS', '0'))      # 0 = the library's choice; 1..4 forces rows/16 per tile (diagnostic)
 ONLY = os.environ.get('CEM_SWEEP_ONLY', '')
-WAVES = int(os.environ.get('CEM_SWEEP_WAVES', '0'))       # 0 = the library's choice; 4 / 8 forces the rollout workgroup form (diagnostic)
 NOGRAPH = bool(os.environ.get('CEM_SWEEP_NOGRAPH'))          # counter passes: every launch its own dispatch, and only a few plans
 
 CFG = [('B1', 60, 2, 5, 500, 25), ('B2', 60, 2, 5, 2000, 30), ('B3', 60, 2, 16, 8192, 30), ('B4', 100, 12, 8, 4096, 50),
@@ -19,7 +18,7 @@ for name, O, A, K, N, H in CFG:
         continue
     pb = synthetic.problem(O, A, K)
     cfg = PlannerConfig(obs_dim=O, act_dim=A, ensemble_size=K, particles=K, n_samples=N, horizon=H, n_elite=N // 10, iterations=5,
-                        scorer=pb['scorer'], act_low=pb['low'], act_high=pb['high'], noise_stddev=1e-3, use_graph=not NOGRAPH, chunks_per_tile=CHUNKS, rollout_waves=WAVES)
+                        scorer=pb['scorer'], act_low=pb['low'], act_high=pb['high'], noise_stddev=1e-3, use_graph=not NOGRAPH, chunks_per_tile=CHUNKS)
     pl = CemPlanner(cfg); pl.set_weights(pb['weights']); pl.set_normaliser(pb['inputs_min'], pb['inputs_max'])
     for i in range(1 if NOGRAPH else 3):
         pl.plan(pb['state'], seed=1, call=i)
@@ -35,7 +34,7 @@ for name, O, A, K, N, H in CFG:
     pl.set_timing(False)
     fl = synthetic.flops_per_row_step(O, A) * K * N * H
     rc, tiles = pl.tiles()
-    r = dict(config=name, waves=pl.waves(), obs=O, act=A, K=K, N=N, H=H, rows=K * N, chunks_per_tile=rc, workgroups=len(tiles), plan_ms=dt * 1e3,
+    r = dict(config=name, obs=O, act=A, K=K, N=N, H=H, rows=K * N, chunks_per_tile=rc, workgroups=len(tiles), plan_ms=dt * 1e3,
              plans_per_s=1 / dt, cand_steps_per_s=5 * N * H / dt, rollout_ms=ms / ln, tflops=fl / (ms / ln * 1e-3) / 1e12,
              frac_of_157_3=fl / (ms / ln * 1e-3) / 157.3e12)
     out.append(r)

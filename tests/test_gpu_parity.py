@@ -810,60 +810,6 @@ def test_segmented_rollout_is_bit_identical(variant, O, A, E, P, N, H, rc, segs)
     assert out[0][4] == out[1][4] and np.isfinite(out[0][0]).all()
 
 
-@pytest.mark.parametrize('variant,O,A,E,P,N,H,L,units,case', [
-    ('cem', 60, 2, 5, 5, 500, 25, 4, 128, None),          # B1
-    ('safe', 60, 2, 5, 5, 96, 12, 4, 128, None),
-    ('safe', 60, 2, 3, 6, 40, 9, 4, 128, None),           # ragged tiles, two particles per member
-    ('cem', 60, 2, 15, 5, 150, 8, 4, 128, None),          # shipped cem_mpc shape: candidates of one particle hit 3 members
-    ('cem', 20, 2, 2, 2, 33, 6, 1, 48, None),             # two input blocks only (slots 2, 3 own no features), one layer, narrow units
-    ('safe', 40, 5, 3, 3, 70, 7, 5, 100, None),           # observation blocks 0..2, the action block with wave 2 / 3
-    ('safe', 60, 2, 5, 5, 96, 8, 4, 128, 'four_kinds_sum'),    # cost kinds beyond the first, non-indicator sum
-    ('cem', 60, 2, 5, 5, 96, 8, 4, 128, 'goal_dist'),          # observe_goal_dist
-    ('cem', 60, 2, 5, 5, 96, 8, 4, 128, 'active_reward_clip'),
-])
-def test_eight_wave_rollout_is_bit_identical(variant, O, A, E, P, N, H, L, units, case):
-    """cem_rollout_w8_kernel (8 waves per tile: one output block per wave, the epilogue split between the two waves of a slot)
-    against the 4-wave kernel: scores, per-row returns, cost bytes, the plan's action and score — bit for bit, in Philox mode."""
-    torch = _torch()
-    pb = hp.scorer_problem(case, O) if case else hp.make_problem(O, A, E, L, seed=91, units=units)
-    out = []
-    for waves in (4, 8):
-        _, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=max(2, N // 10), I=2, variant=variant, post=0.3, chunks_per_tile=1,
-                             rollout_segments=1, rollout_waves=waves)
-        pl = hp.make_planner(pb, pcfg)
-        assert pl.waves() == waves
-        pl.plan_begin(pb['state'], seed=5, call=3)
-        pl.plan_rollout(0)
-        pl.plan_select(0)
-        pl.plan_rollout(1)
-        a, sc, it = pl.plan_end()
-        out.append((pl.scores_local().cpu().numpy().copy(), pl.returns().cpu().numpy().copy(),
-                    pl.costs().cpu().numpy().copy() if variant == 'safe' else None, a, sc))
-        pl.close()
-    np.testing.assert_array_equal(out[0][0], out[1][0])
-    np.testing.assert_array_equal(out[0][1], out[1][1])
-    if variant == 'safe':
-        np.testing.assert_array_equal(out[0][2], out[1][2])
-    np.testing.assert_array_equal(out[0][3], out[1][3])
-    assert out[0][4] == out[1][4] and np.isfinite(out[0][0]).all()
-
-
-def test_eight_wave_form_is_chosen_only_where_it_fits():
-    """Automatic choice: at most one one-chunk tile per CU and obs+act <= 64; an explicit request elsewhere is refused."""
-    from ethz_safe_learning_amd import CemPlanner
-    from ethz_safe_learning_amd._capi import CemError
-    pb = hp.make_problem(seed=3)
-    for N, waves in ((500, 8), (2000, 4)):                  # B1: 160 tiles; B2: 625 tiles (pinned + floating segments)
-        _, pcfg = hp.configs(pb, N=N, H=8, P=5, E=5, k=N // 10, I=1)
-        pl = hp.make_planner(pb, pcfg)
-        assert pl.waves() == waves
-        pl.close()
-    wide = hp.make_problem(100, 12, 2, 2, seed=3)
-    _, pcfg = hp.configs(wide, N=32, H=4, P=2, E=2, k=4, I=1, rollout_waves=8)
-    with pytest.raises(CemError):
-        CemPlanner(pcfg)
-
-
 def test_select_modes_agree_on_a_whole_plan():
     """The one-workgroup select and the multi-workgroup chain inside complete plans (early stop included): the same iteration
     count, best action / score and mu / sigma to fp32 rounding.  (Exact equality of one select on given scores, ties included, is
