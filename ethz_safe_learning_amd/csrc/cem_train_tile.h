@@ -198,6 +198,16 @@ __global__ __launch_bounds__(64 * CEM_TT_WAVES) void cem_train_tile_kernel(const
         if (own) tt_load<1>(wb[0], op);
     }
 
+    // every bias this wave will start an accumulator from, requested now: a load issued right before its stage would expose a full
+    // L2 round trip at each of the L + 1 forward stages
+    f4 bias[L], bias_mu4, bias_v4;
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int o = mb + 4 * c.q + r; bias[l][r] = W[offb(l) + (o < U ? o : 0)]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int o = mb + 4 * c.q + r; bias_mu4[r] = W[obmu + (o < O ? o : 0)]; bias_v4[r] = W[obv + (o < O ? o : 0)]; }
+
     if (tid < CEM_TROWS) {
         const int rr = tid < cnt ? tid : cnt - 1;                  // rows past the end repeat the last one; their gradients are masked to zero
         rows_s[tid] = p.perm ? p.perm[(size_t)m * p.nperm + p.offset + chunk0 + row0 + rr] : p.offset + chunk0 + row0 + rr;
@@ -230,9 +240,8 @@ __global__ __launch_bounds__(64 * CEM_TT_WAVES) void cem_train_tile_kernel(const
             if (ownO) tt_load<2>(wb[(l + 1) & 1], op);
         }
         f4 acc[1];
-        const gcptr bl = W + offb(l);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int o = mb + 4 * c.q + r; acc[0][r] = o < U ? bl[o] : 0.f; }
+        for (int r = 0; r < 4; ++r) { const int o = mb + 4 * c.q + r; acc[0][r] = o < U ? bias[l][r] : 0.f; }
         if (own) tt_mfma<1>(acc, wb[l & 1], act + (size_t)l * CEM_TT_NB * CEM_TT_BLK, c);
         f4 h = acc[0];
 #pragma unroll
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(64 * CEM_TT_WAVES) void cem_train_tile_kernel(const
     if (ownO) {                                                            // wave-uniform
         f4 acc[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int o = mb + 4 * c.q + r; acc[0][r] = o < O ? W[obmu + o] : 0.f; acc[1][r] = o < O ? W[obv + o] : 0.f; }
+        for (int r = 0; r < 4; ++r) { const int o = mb + 4 * c.q + r; acc[0][r] = o < O ? bias_mu4[r] : 0.f; acc[1][r] = o < O ? bias_v4[r] : 0.f; }
         tt_mfma<2>(acc, wb[L & 1], hL, c);
         f4 dmu = (f4){0.f, 0.f, 0.f, 0.f}, dv = dmu;
 #pragma unroll
