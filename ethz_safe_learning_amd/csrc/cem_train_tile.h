@@ -116,28 +116,30 @@ __device__ __forceinline__ float tt_gather(const char *blk, const int P, const T
     return *reinterpret_cast<const float *>(blk + (c.j >> 2) * 288 + ((4 * P + c.q) * 4 + (c.j & 3)) * 4);
 }
 
-// dW[in][out] partial of one layer: this wave owns the in-feature block Gi = w (< nIn) and all eight out blocks:
+// dW[in][out] partial of one layer: this wave owns the in-feature block Gi = w (< nIn) and the out blocks F < NF (8, or 4 where the
+// matrix is at most 64 wide — the heads of a 60-dimensional observation: half the MFMAs):
 // dW[16Gi + 4q + r][16F + j] = sum over rows.  hsrc / dsrc: LDS activations of the layer's input / the gradient of its output.
-__device__ __forceinline__ void tt_dw(const char *hsrc, const char *dsrc, const int nIn, const int inDim, const int outDim,
-                                      float *Gw, const int ldw, const TtCtx &c)
+template <int NF>
+__device__ __forceinline__ void tt_dw_n(const char *hsrc, const char *dsrc, const int nIn, const int inDim, const int outDim,
+                                        float *Gw, const int ldw, const TtCtx &c)
 {
 #ifdef CEM_TT_DBG_NODW
     return;
 #endif
     const int Gi = c.w;
     if (Gi < nIn) {                                                           // wave-uniform
-        f4 acc[CEM_TT_NB];
+        f4 acc[NF];
 #pragma unroll
-        for (int F = 0; F < CEM_TT_NB; ++F) acc[F] = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int F = 0; F < NF; ++F) acc[F] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int P = 0; P < 4; ++P) {
             const float a = tt_gather(hsrc + Gi * CEM_TT_BLK, P, c);
 #pragma unroll
-            for (int F = 0; F < CEM_TT_NB; ++F)                               // out blocks past the width hold zeros
+            for (int F = 0; F < NF; ++F)                                      // out blocks past the width hold zeros
                 acc[F] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, tt_gather(dsrc + F * CEM_TT_BLK, P, c), acc[F], 0, 0, 0);
         }
 #pragma unroll
-        for (int F = 0; F < CEM_TT_NB; ++F) {
+        for (int F = 0; F < NF; ++F) {
             const int n = 16 * F + c.j;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -151,6 +153,12 @@ __device__ __forceinline__ void tt_dw(const char *hsrc, const char *dsrc, const 
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void tt_dw(const char *hsrc, const char *dsrc, const int nIn, const int inDim, const int outDim,
+                                      float *Gw, const int ldw, const TtCtx &c)
+{
+    if (outDim <= 64) tt_dw_n<4>(hsrc, dsrc, nIn, inDim, outDim, Gw, ldw, c);
+    else tt_dw_n<8>(hsrc, dsrc, nIn, inDim, outDim, Gw, ldw, c);
 }
 
 template <int L>
@@ -167,6 +175,7 @@ __global__ __launch_bounds__(64 * CEM_TT_WAVES) void cem_train_tile_kernel(const
     const int row0 = part * CEM_TROWS;
     const int cnt = Bt - row0 < CEM_TROWS ? Bt - row0 : CEM_TROWS;
     if (cnt <= 0) return;                          // a short minibatch: the Adam kernel only adds the parts that exist
+    CEM_TR_STAMP(0);
     TtCtx c; c.lane = tid & 63; c.q = c.lane >> 4; c.j = c.lane & 15; c.w = __builtin_amdgcn_readfirstlane(tid >> 6); c.cnt = cnt;
     const gcptr W = (gcptr)(p.W + (size_t)m * p.nat);
     float *G = p.grad + (size_t)part * p.gpart + (size_t)m * p.nat;
@@ -229,6 +238,7 @@ __global__ __launch_bounds__(64 * CEM_TT_WAVES) void cem_train_tile_kernel(const
         *reinterpret_cast<f4 *>(dhd + (CEM_TT_NB + c.w) * CEM_TT_BLK + CEM_TT_LANE(c)) = (f4){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
+    CEM_TR_STAMP(1);
 
     // ---- forward (mlp_ensemble.py:18-22,59-61): wave w computes output block w of every layer ----------------------------------
 #pragma unroll
@@ -248,6 +258,7 @@ __global__ __launch_bounds__(64 * CEM_TT_WAVES) void cem_train_tile_kernel(const
         for (int r = 0; r < 4; ++r) h[r] = (mb + 4 * c.q + r < U) ? fmaxf(h[r], 0.f) : 0.f;     // units past U stay exactly zero
         *reinterpret_cast<f4 *>(act + (size_t)(l + 1) * CEM_TT_NB * CEM_TT_BLK + c.w * CEM_TT_BLK + CEM_TT_LANE(c)) = h;
         __syncthreads();
+        CEM_TR_STAMP(2 + l);
     }
     const char *hL = act + (size_t)L * CEM_TT_NB * CEM_TT_BLK;
 
@@ -299,6 +310,7 @@ __global__ __launch_bounds__(64 * CEM_TT_WAVES) void cem_train_tile_kernel(const
         float *lp = p.loss_part + (((size_t)blockIdx.y * p.E + m) * CEM_TPARTS + part) * 2;
         lp[0] = a; lp[1] = b;
     }
+    CEM_TR_STAMP(2 + L);
     if (!p.train) return;
 
     // ---- backward ---------------------------------------------------------------------------------------------------------
@@ -326,6 +338,7 @@ __global__ __launch_bounds__(64 * CEM_TT_WAVES) void cem_train_tile_kernel(const
     tt_dw(hL, dhd, nbU, U, O, G + oWmu, O, c);
     tt_dw(hL, dhd + CEM_TT_NB * CEM_TT_BLK, nbU, U, O, G + oWv, O, c);
     __syncthreads();
+    CEM_TR_STAMP(3 + L);
 #pragma unroll
     for (int l = L - 1; l >= 0; --l) {
         const int st = L + 3 + (L - 1 - l);                                 // the stage that consumes W_l
@@ -353,5 +366,6 @@ __global__ __launch_bounds__(64 * CEM_TT_WAVES) void cem_train_tile_kernel(const
         }
         tt_dw(hin, dcur, nIn, in, U, G + offW(l), U, c);                    // dW_l = h_{l-1}^T dh_l
         if (l > 0) __syncthreads();
+        CEM_TR_STAMP(4 + L + (L - 1 - l));
     }
 }

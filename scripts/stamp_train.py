@@ -19,6 +19,12 @@ for i in range(3):
 tr.synchronize()
 ws = tr._ws_view
 st = ws[ws.numel() - 256:].view(torch.int64).cpu().numpy().astype(np.float64)
-names = ['gather', 'forward hidden layers', 'forward heads', 'nll + grads', '(branch)', 'backward heads', 'backward layers']
-print('  '.join('%s %.1f us' % (nm, (st[i + 1] - st[i]) / 2400.0) for i, nm in enumerate(names)), ' total %.1f us' % ((st[7] - st[0]) / 2400.0))
-print('inside the %d GEMM tile passes: first slab into LDS %.1f us, k loop %.1f us, epilogue %.1f us' % (st[11], st[8] / 2400.0, st[9] / 2400.0, st[10] / 2400.0))
+if os.environ.get('CEM_TRAIN_GEMM_KERNEL'):
+    names = ['gather', 'forward hidden layers', 'forward heads', 'nll + grads', '(branch)', 'backward heads', 'backward layers']
+    print('  '.join('%s %.1f us' % (nm, (st[i + 1] - st[i]) / 2400.0) for i, nm in enumerate(names)), ' total %.1f us' % ((st[7] - st[0]) / 2400.0))
+    print('inside the %d GEMM tile passes: first slab into LDS %.1f us, k loop %.1f us, epilogue %.1f us' % (st[11], st[8] / 2400.0, st[9] / 2400.0, st[10] / 2400.0))
+else:   # the tile kernel (cem_train_tile.h): workgroup 0, wave 0
+    names = ['rows + inputs into LDS'] + ['forward layer %d' % l for l in range(L)] + ['heads + NLL + its gradients', 'dh_L + head dW'] + \
+            ['backward layer %d (dh + dW)' % l for l in range(L - 1, -1, -1)]
+    print('\n'.join('%-32s %.2f us' % (nm, (st[i + 1] - st[i]) / 2400.0) for i, nm in enumerate(names)))
+    print('total %.1f us' % ((st[len(names)] - st[0]) / 2400.0))
