@@ -3,6 +3,8 @@ BASELINE shapes; these sweep the corners nobody picked by hand (odd widths and d
 64, members that split a particle, every tile size, forced horizon segments, both objectives, sampling / scaling off) with a
 fixed seed per case, so a failure names a reproducible configuration.  Oracle = oracle/cem_oracle.py in fp64 (PARITY UNPINNED:
 the oracle is this repo's restatement of the reference)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -11,6 +13,8 @@ from tests import helpers as hp
 from tests.test_gpu_parity import _run_iteration, _score_err
 
 pytestmark = pytest.mark.gpu
+# CEM_FUZZ_SCALE=n multiplies the number of seeds of every sweep (a longer one-off hunt; the default suite stays seconds long)
+SCALE = int(os.environ.get('CEM_FUZZ_SCALE', '1'))
 
 
 def _random_rollout_case(seed):
@@ -31,7 +35,7 @@ def _random_rollout_case(seed):
                 scale=bool(rng.random() < 0.8), post=float(rng.choice([0.15, 0.3, 0.5])))
 
 
-@pytest.mark.parametrize('seed', range(32))
+@pytest.mark.parametrize('seed', range(32 * SCALE))
 def test_random_shape_rollout_scores(seed):
     c = _random_rollout_case(seed)
     O, A, E, P, N, H = c['O'], c['A'], c['E'], c['P'], c['N'], c['H']
@@ -61,7 +65,7 @@ def _random_training_case(seed):
                 units=int(rng.choice([8, 17, 31, 48, 64, 99, 128])), kernel=str(rng.choice(['tile', 'gemm'])))
 
 
-@pytest.mark.parametrize('seed', range(16))
+@pytest.mark.parametrize('seed', range(16 * SCALE))
 def test_random_shape_training_steps(seed, monkeypatch):
     import torch
     from ethz_safe_learning_amd.trainer import CemTrainer
@@ -118,7 +122,7 @@ def _random_plan_case(seed):
                 select_mode=int(rng.choice([0, 1, 2])), use_graph=False)
 
 
-@pytest.mark.parametrize('seed', range(24))
+@pytest.mark.parametrize('seed', range(24 * SCALE))
 def test_random_shape_whole_plan_teacher_forced(seed):
     """Every iteration of a stepwise plan, each stage checked against the oracle on the GPU's OWN inputs (so a near-tie can never
     excuse a mismatch): sampled actions from the GPU's mu / sigma (bit-exact), the elite SET from the GPU's scores (exact, ties
