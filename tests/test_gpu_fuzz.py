@@ -168,3 +168,52 @@ def test_random_shape_whole_plan_teacher_forced(seed):
         np.testing.assert_array_equal(a, best + eo * np.float32(c['noise']), err_msg=str(c))
         assert s == best_score, (c, s, best_score)
     pl.close()
+
+
+def _random_shard_case(seed):
+    rng = np.random.default_rng(13000 + seed)
+    W = int(rng.choice([2, 3, 4, 8]))
+    E = int(rng.integers(1, 6))
+    P = E * int(rng.integers(1, 3)) if rng.random() < 0.6 else int(rng.integers(1, 5))
+    per = int(rng.integers(1, 60))
+    N = W * per
+    if (P * N) % E:
+        N = W * per * E
+    A = int(rng.integers(1, 4))
+    O = int(rng.choice([9, 40, 60, 100]))
+    return dict(W=W, E=E, P=P, N=N, O=O, A=A, H=int(rng.integers(1, 9)), variant=str(rng.choice(['cem', 'safe'])),
+                rc_full=int(rng.integers(0, 5)), rc_shard=int(rng.integers(0, 5)), seg=int(rng.choice([0, 1, 2, 3])))
+
+
+@pytest.mark.parametrize('seed', range(16 * SCALE))
+def test_random_shape_shard_and_tile_invariance(seed):
+    """Philox mode: the scores (and cost bytes) of a population do not depend on how it is cut — rank shards of a world of W
+    (each with its own handle, tile size and segment count) concatenate to the single-rank result bit for bit: tiles, members
+    and noise are keyed on GLOBAL candidate / row indices."""
+    import torch
+    c = _random_shard_case(seed)
+    W, E, P, N, O, A, H = c['W'], c['E'], c['P'], c['N'], c['O'], c['A'], c['H']
+    pb = hp.make_problem(O, A, E, 3, seed=500 + seed, units=96)
+
+    def run(world, rank, rc, seg):
+        _, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=max(1, N // 10), I=1, variant=c['variant'], post=0.3, world_size=world, rank=rank,
+                             chunks_per_tile=rc, rollout_segments=seg)
+        pl = hp.make_planner(pb, pcfg)
+        pl.plan_begin(pb['state'], seed=77, call=seed)
+        pl.plan_rollout(0)
+        torch.cuda.synchronize()
+        out = (pl.scores_local().cpu().numpy().copy(), pl.returns().cpu().numpy().copy(),
+               pl.costs().cpu().numpy().copy() if c['variant'] == 'safe' else None)
+        pl.close()
+        return out
+    full = run(1, 0, c['rc_full'], 0)
+    assert np.isfinite(full[0]).all(), c
+    parts = [run(W, r, c['rc_shard'], c['seg']) for r in range(W)]
+    np.testing.assert_array_equal(np.concatenate([p_[0] for p_ in parts]), full[0], err_msg=str(c))
+    # per-row returns are particle-major within a rank: [P][N/W]
+    Nl = N // W
+    ret = np.concatenate([p_[1].reshape(P, Nl) for p_ in parts], axis=1).reshape(-1)
+    np.testing.assert_array_equal(ret, full[1].reshape(-1), err_msg=str(c))
+    if c['variant'] == 'safe':
+        cost = np.concatenate([p_[2].reshape(H, P, Nl) for p_ in parts], axis=2).reshape(H, -1)
+        np.testing.assert_array_equal(cost, full[2].reshape(H, -1), err_msg=str(c))
