@@ -217,3 +217,45 @@ def test_random_shape_shard_and_tile_invariance(seed):
     if c['variant'] == 'safe':
         cost = np.concatenate([p_[2].reshape(H, P, Nl) for p_ in parts], axis=2).reshape(H, -1)
         np.testing.assert_array_equal(cost, full[2].reshape(H, -1), err_msg=str(c))
+
+
+def _random_unfold_case(seed):
+    rng = np.random.default_rng(17000 + seed)
+    A = int(rng.integers(1, 9))
+    O = min(int(rng.choice([3, 6, 20, 47, 60, 64, 65, 100, 120])), 128 - A)
+    E = int(rng.integers(1, 7))
+    return dict(O=O, A=A, E=E, L=int(rng.integers(1, 6)), B=E * int(rng.integers(1, 70)), H=int(rng.integers(1, 8)),
+                units=int(rng.choice([16, 40, 64, 101, 128])), sampling=bool(rng.random() < 0.7), scale=bool(rng.random() < 0.7),
+                variant=str(rng.choice(['cem', 'safe'])))
+
+
+@pytest.mark.parametrize('seed', range(16 * SCALE))
+def test_random_shape_unfold_and_objective_ops(seed):
+    """TransitionModel.unfold_sequences on arbitrary per-row start states (cem_unfold_sequences) against the fp64 oracle, and
+    compute_objective on the trajectory it returns against the oracle's objective on the same tensor."""
+    c = _random_unfold_case(seed)
+    O, A, E, L, B, H = c['O'], c['A'], c['E'], c['L'], c['B'], c['H']
+    pb = hp.make_problem(O, A, E, L, seed=600 + seed, units=c['units'])
+    P = E
+    ocfg, pcfg = hp.configs(pb, N=B // P, H=H, P=P, E=E, k=1, I=1, sampling=c['sampling'], scale=c['scale'], variant=c['variant'], post=0.5)
+    pl = hp.make_planner(pb, pcfg)
+    rng = np.random.default_rng(seed)
+    s0 = (pb['state'][None, :] + 0.05 * rng.standard_normal((B, O))).astype(np.float32)
+    acts = rng.uniform(-1, 1, (B, H, A)).astype(np.float32)
+    eps = rng.standard_normal((H, B, O)).astype(np.float32)
+    traj_dev = pl.unfold_sequences(s0, acts, eps_model=eps)
+    traj = traj_dev.cpu().numpy()
+    members = o.member_of_rows(B, E)
+    w64 = o.cast_weights(pb['weights'], np.float64)
+    ref64 = o.unfold_sequences(s0.astype(np.float64), acts.astype(np.float64), w64, members, pb['inputs_min'], pb['inputs_max'],
+                               eps.astype(np.float64), c['scale'], c['sampling'])
+    np.testing.assert_array_equal(traj[:, 0], s0, err_msg=str(c))
+    assert np.abs(traj - ref64).max() <= 5e-6 * max(1.0, np.abs(ref64).max()), (c, float(np.abs(traj - ref64).max()))
+    got = pl.compute_objective(traj_dev).cpu().numpy()
+    t64 = traj.astype(np.float64)
+    N = B // P
+    ref = o.compute_objective_safe(t64, P, N, pb['scorer'], 0.5) if c['variant'] == 'safe' else o.compute_objective_cem(t64, P, N, pb['scorer'])
+    ok = o.threshold_margins(t64, pb['scorer']).reshape(P, N).min(axis=0) > 1e-5
+    if ok.any():
+        assert _score_err(got[ok], ref[ok]) <= 1.0, (c, float(np.abs(got - ref)[ok].max()))
+    pl.close()
