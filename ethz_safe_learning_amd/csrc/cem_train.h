@@ -1,4 +1,6 @@
-// cem_train.h — ensemble training step on the device: MlpEnsemble.training_step / validation_step,
+// cem_train.h — ensemble training step on the device: shared definitions (TrainParams, the Adam kernel) and the
+// GEMM-by-GEMM step kernel — since round 2 the FALLBACK (more than 6 layers, or CEM_TRAIN_GEMM_KERNEL=1); the default step is the
+// rollout-style kernel of cem_train_tile.h.  MlpEnsemble.training_step / validation_step,
 // simba/models/mlp_ensemble.py:134-155, with negative_log_likelihood (:64-67) and
 // tf.keras.optimizers.Adam(lr, clipvalue=1.0, epsilon=1e-5) (:113-117).
 //
