@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""End to end: what one iteration of the reference's main experiment costs with this planner in the loop.
+config/point_goal1.yaml = the reference's experiment (safe CEM-MPC, N=500 P=45 E=15 H=8 I<=9; 1000 interaction steps at
+action_repeat 6 per iteration, then MlpEnsemble.fit: 5000 Adam steps x batch 64 on the most recent 30000 transitions) on this
+repo's Point-Goal stand-in for safety_gym.  Wall time per phase of iterations after the random warm-up: planner calls
+(Policy.generate_action), model fit, everything else (the Python environment, replay buffer, bookkeeping).
+usage: python scripts/time_agent_iteration.py [iterations=2]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    from ethz_safe_learning_amd.config.config import load_config_or_die
+    from ethz_safe_learning_amd.simba.agents.agent_factory import make_agent
+    from ethz_safe_learning_amd.simba.environment_utils.environment_factory import make_environment
+    params = load_config_or_die(os.path.join(ROOT, 'ethz_safe_learning_amd', 'config'), 'point_goal1.yaml')
+    np.random.seed(1)
+    env = make_environment(params, seed=1)
+    for p in params['policies'].values():
+        p.setdefault('seed', 1)
+    agent = make_agent(params, env)
+    agent.build_graph()
+    clock = dict(plan=0.0, fit=0.0, plans=0, fits=0)
+
+    def timed(obj, name, key, count):
+        fn = getattr(obj, name)
+
+        def wrapper(*a, **kw):
+            t0 = time.perf_counter()
+            try:
+                return fn(*a, **kw)
+            finally:
+                clock[key] += time.perf_counter() - t0
+                clock[count] += 1
+        setattr(obj, name, wrapper)
+    timed(agent.policy, 'generate_action', 'plan', 'plans')
+    timed(agent.model, 'fit', 'fit', 'fits')
+    # warm-up: the random policy fills the buffer, then the first fit (which also builds the trainer handle)
+    t0 = time.perf_counter()
+    while not agent.warm:
+        agent.interact(env)
+    agent.update()
+    warm_s = time.perf_counter() - t0
+    out = []
+    for it in range(n_iter):
+        for k in clock:
+            clock[k] = 0 if isinstance(clock[k], int) else 0.0
+        t0 = time.perf_counter()
+        agent.interact(env)
+        agent.update()
+        total = time.perf_counter() - t0
+        r = dict(iteration=it, total_s=round(total, 3), plan_s=round(clock['plan'], 3), plans=clock['plans'],
+                 ms_per_plan=round(1e3 * clock['plan'] / max(clock['plans'], 1), 3), fit_s=round(clock['fit'], 3), fits=clock['fits'],
+                 other_s=round(total - clock['plan'] - clock['fit'], 3), buffer=len(agent.replay_buffer) if hasattr(agent.replay_buffer, '__len__') else None)
+        out.append(r)
+        print(json.dumps(r), flush=True)
+    print(json.dumps(dict(warmup_and_first_fit_s=round(warm_s, 2), policy=params['options'].get('agent'),
+                          safe_cem_mpc=params['policies'].get('safe_cem_mpc'))), flush=True)
+
+
+if __name__ == '__main__':
+    main()
