@@ -3,6 +3,7 @@
 #include "cem_device.h"
 #include "cem_train.h"
 #include "cem_train_tile.h"
+#include "cem_rollout_wide.h"
 #include "../../include/cem_mpc.h"
 
 #include <dlfcn.h>
@@ -25,6 +26,7 @@ struct Dims {
     int O, A, Din, U, L, E, P, N, H, k, I, W, R;
     int Nloc, n_off, Bloc, Btot;
     int KB_in, KB_obs, NFW, KF0;     // KF0 = 4*NFW: layer-0 groups per wave, zero padded so every stage is a multiple of 4
+    bool wide;                       // units > 128: the width-generic rollout kernel on the natural weight blob (cem_rollout_wide.h)
     int wave_groups[4]; uint32_t wave_off_f4[4]; uint32_t member_stride_f4;
     size_t nat_member_floats;
 };
@@ -38,7 +40,7 @@ int validate(const cem_config_t *c)
         c->n_elite < 1 || c->n_elite > c->n_samples || c->world_size < 1 || c->rank < 0 || c->rank >= c->world_size)
         return CEM_ERR_INVALID_ARG;
     if (c->units < 1) return CEM_ERR_INVALID_ARG;
-    if (c->units > CEM_U) return CEM_ERR_UNSUPPORTED;     // narrower layers run zero-padded to 128 (exactly: the padding adds zeros)
+    if (c->units > CEM_WIDE_U) return CEM_ERR_UNSUPPORTED;  // <= 128: the fast kernel (narrower layers run zero-padded, exactly); 129..256: cem_rollout_wide.h
     if (c->obs_dim + c->act_dim > CEM_U) return CEM_ERR_UNSUPPORTED;
     if (c->n_samples % c->world_size != 0) return CEM_ERR_INVALID_ARG;
     if (((long long)c->particles * c->n_samples) % c->ensemble_size != 0) return CEM_ERR_SPLIT;
@@ -74,6 +76,7 @@ Dims make_dims(const cem_config_t *c)
     d.W = c->world_size; d.R = c->rank;
     d.Nloc = d.N / d.W; d.n_off = d.R * d.Nloc; d.Bloc = d.P * d.Nloc; d.Btot = d.P * d.N;
     d.KB_in = (d.Din + 15) / 16; d.KB_obs = (d.O + 15) / 16; d.NFW = (d.KB_in + 3) / 4; d.KF0 = 4 * d.NFW;
+    d.wide = d.U > CEM_U;
     uint32_t off = 0;
     for (int w = 0; w < 4; ++w) {
         int g = d.KF0 + CEM_NG * (d.L - 1);
@@ -291,10 +294,10 @@ struct Plan { int rc, n_tiles, n_seg, seg_len, n_pinned; };
 Plan make_plan(const cem_config_t *c, const Dims &d)
 {
     Plan pl{};
-    pl.rc = c->chunks_per_tile ? c->chunks_per_tile : auto_chunks(d, c->rollout_segments);
+    pl.rc = d.wide ? 1 : (c->chunks_per_tile ? c->chunks_per_tile : auto_chunks(d, c->rollout_segments));   // the wide kernel: 16-row tiles
     std::vector<Tile6> t; build_plan_tiles(d, pl.rc, t);
     pl.n_tiles = (int)t.size();
-    pl.n_seg = segments_for(d, pl.rc, t.size(), c->rollout_segments);
+    pl.n_seg = d.wide ? 1 : segments_for(d, pl.rc, t.size(), c->rollout_segments);
     pl.seg_len = (d.H + pl.n_seg - 1) / pl.n_seg;
     pl.n_seg = (d.H + pl.seg_len - 1) / pl.seg_len;
     // tiles every CU gets the same number of stay whole ("pinned"); only the remainder floats in segments
@@ -316,7 +319,7 @@ Layout make_layout(const cem_config_t *c, const Dims &d, size_t max_tiles)
     l.returns = take((size_t)d.Bloc * 4);
     l.costs = take((size_t)d.H * d.Bloc);
     l.result = take(64 * 4);
-    l.wpack = take((size_t)d.E * d.member_stride_f4 * 16);
+    l.wpack = take(d.wide ? (size_t)d.E * d.nat_member_floats * 4 : (size_t)d.E * d.member_stride_f4 * 16);   // wide: the natural blob itself
     l.bias_h = take((size_t)d.E * d.L * CEM_U * 4);
     l.bias_mu = take((size_t)d.E * CEM_U * 4);
     l.bias_var = take((size_t)d.E * CEM_U * 4);
@@ -421,7 +424,7 @@ const char *cem_status_string(int s)
     switch (s) {
     case CEM_OK: return "ok";
     case CEM_ERR_INVALID_ARG: return "invalid argument";
-    case CEM_ERR_UNSUPPORTED: return "unsupported configuration (units <= 128, obs+act <= 128, task 'goal')";
+    case CEM_ERR_UNSUPPORTED: return "unsupported configuration (units <= 256, obs+act <= 128, task 'goal')";
     case CEM_ERR_SPLIT: return "particles*n_samples is not divisible by ensemble_size (tf.split would raise)";
     case CEM_ERR_WORKSPACE: return "workspace too small or misaligned";
     case CEM_ERR_HIP: return "HIP runtime error (see cem_last_hip_error)";
@@ -444,6 +447,7 @@ size_t cem_packed_weight_floats(const cem_config_t *cfg)
 {
     if (validate(cfg) != CEM_OK) return 0;
     const Dims d = make_dims(cfg);
+    if (d.wide) return 0;                               // the wide kernel reads the natural blob: nothing is packed
     return (size_t)d.member_stride_f4 * 4 * d.E;
 }
 
@@ -459,6 +463,7 @@ int cem_pack_weights_host(const cem_config_t *cfg, const float *blob, float *pac
     int st = validate(cfg); if (st) return st;
     if (!blob || !packed) return CEM_ERR_INVALID_ARG;
     const Dims d = make_dims(cfg);
+    if (d.wide) return CEM_ERR_UNSUPPORTED;
     for (int m = 0; m < d.E; ++m) pack_member(d, blob + (size_t)m * d.nat_member_floats, packed + (size_t)m * d.member_stride_f4 * 4);
     return CEM_OK;
 }
@@ -616,6 +621,12 @@ int cem_planner_set_weights(cem_planner_t *h, const float *blob, size_t n_floats
     if (!h || !blob) return CEM_ERR_INVALID_ARG;
     const Dims &d = h->d;
     if (n_floats != d.nat_member_floats * d.E) return CEM_ERR_INVALID_ARG;
+    if (d.wide) {                                       // the wide kernel reads the natural blob as it is
+        HIPCHK(hipMemcpyAsync(h->ws + h->lay.wpack, blob, n_floats * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->have_weights = true;
+        return CEM_OK;
+    }
     std::vector<float> packed((size_t)d.member_stride_f4 * 4 * d.E);
     std::vector<float> bh((size_t)d.E * d.L * CEM_U, 0.f), bmu((size_t)d.E * CEM_U, 0.f), bvar((size_t)d.E * CEM_U, 0.f);
     const NatOff no = nat_offsets(d);
@@ -695,6 +706,14 @@ hipError_t launch_rollout(int rc, int nfw, const RolloutParams &p, int n_tiles, 
     return hipErrorInvalidValue;
 }
 
+hipError_t launch_rollout_wide(const cem_planner *h, const RolloutParams &rp, int n_tiles)
+{
+    WideParams wp; wp.r = rp;
+    wp.wnat = (const float *)(h->ws + h->lay.wpack); wp.nat = (uint32_t)h->d.nat_member_floats; wp.U = h->d.U;
+    hipLaunchKernelGGL(cem_rollout_wide_kernel, dim3(n_tiles), dim3(256), CEM_WIDE_SMEM, h->stream, wp);
+    return hipGetLastError();
+}
+
 void fill_rollout_common(const cem_planner *h, RolloutParams &p)
 {
     const Dims &d = h->d; const Layout &l = h->lay; char *ws = h->ws;
@@ -749,7 +768,8 @@ int enqueue_rollout(cem_planner *h, int it)
     rp.stamps = (long long *)(ws + l.stamps);
     size_t e0 = 0;
     if (h->timing) { e0 = h->ev_kind.size() * 2; h->ev_kind.push_back({(int)e0, 0}); hipEventRecord(get_event(h, e0), h->stream); }
-    if (rp.eps_model) HIPCHK(launch_rollout<1>(h->rc, d.NFW, rp, h->n_tiles, h->stream));
+    if (d.wide) HIPCHK(launch_rollout_wide(h, rp, h->n_tiles));
+    else if (rp.eps_model) HIPCHK(launch_rollout<1>(h->rc, d.NFW, rp, h->n_tiles, h->stream));
     else if (queued) {
         rp.seg_queue = sp.seg_queue; rp.seg_flags = sp.seg_flags; rp.seg_state = (f4 *)(ws + l.seg_state);
         rp.seg_len = h->seg_len; rp.n_seg = h->n_seg; rp.n_tiles = h->n_tiles; rp.n_pinned = h->n_pinned;
@@ -1042,7 +1062,7 @@ int cem_unfold_sequences(cem_planner_t *h, const float *s0_dev, const float *act
     if (n_rows % d.E != 0) return CEM_ERR_SPLIT;
     if ((long long)n_rows * (horizon + 1) * d.O > 0x7fffffff00ll) return CEM_ERR_UNSUPPORTED;
     const int chunk = n_rows / d.E;
-    const int rc = n_rows >= 256 * 64 ? 4 : (n_rows >= 256 * 32 ? 2 : 1);
+    const int rc = d.wide ? 1 : (n_rows >= 256 * 64 ? 4 : (n_rows >= 256 * 32 ? 2 : 1));
     std::vector<Tile6> tiles;
     for (int m = 0; m < d.E; ++m)
         for (int r = m * chunk; r < (m + 1) * chunk; r += 16 * rc) {
@@ -1060,7 +1080,7 @@ int cem_unfold_sequences(cem_planner_t *h, const float *s0_dev, const float *act
     rp.tiles = dt; rp.s0 = s0_dev; rp.actions = actions_dev; rp.eps_model = eps_model_dev; rp.ret = ret; rp.costs = nullptr;
     rp.traj = traj_out_dev; rp.mu_out = mu_out_dev; rp.sd_out = sd_out_dev;
     rp.H = horizon; rp.Bloc = n_rows; rp.Btot = n_rows; rp.it = 0; rp.variant = 0; rp.check_done = 0;
-    hipError_t e = launch_rollout<1>(rc, d.NFW, rp, (int)tiles.size(), h->stream);
+    hipError_t e = d.wide ? launch_rollout_wide(h, rp, (int)tiles.size()) : launch_rollout<1>(rc, d.NFW, rp, (int)tiles.size(), h->stream);
     hipError_t e2 = hipStreamSynchronize(h->stream);
     HIPCHK(e); HIPCHK(e2);
     return CEM_OK;
@@ -1160,7 +1180,7 @@ int validate_train(const cem_train_config_t *c)
     if (!c || c->abi_version != CEM_ABI_VERSION) return CEM_ERR_INVALID_ARG;
     if (c->inputs_dim < 1 || c->outputs_dim < 1 || c->n_layers < 1 || c->ensemble_size < 1 || c->batch_size < 1) return CEM_ERR_INVALID_ARG;
     if (c->units < 1) return CEM_ERR_INVALID_ARG;
-    if (c->units > CEM_U || c->inputs_dim > CEM_U || c->outputs_dim > CEM_U || c->batch_size > CEM_TB) return CEM_ERR_UNSUPPORTED;
+    if (c->units > CEM_TWIDE || c->inputs_dim > CEM_U || c->outputs_dim > CEM_U || c->batch_size > CEM_TB) return CEM_ERR_UNSUPPORTED;
     return CEM_OK;
 }
 size_t train_nat(const cem_train_config_t *c)
@@ -1172,7 +1192,7 @@ void train_layout(cem_trainer *t)
 {
     const cem_train_config_t &c = t->cfg;
     t->nat = train_nat(&c);
-    t->scratch_pm = (size_t)(c.n_layers + 8) * CEM_TROWS * CEM_TS;       // per (member, row part) workgroup
+    t->scratch_pm = (size_t)(c.n_layers + 8) * CEM_TROWS * (c.units > CEM_TS ? CEM_TWIDE : CEM_TS);       // per (member, row part) workgroup
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
     t->oW = take(t->nat * c.ensemble_size * 4); t->oM = take(t->nat * c.ensemble_size * 4); t->oV = take(t->nat * c.ensemble_size * 4);
@@ -1210,6 +1230,7 @@ void fill_train_params(const cem_trainer *t, TrainParams &p)
     p.D = c.inputs_dim; p.O = c.outputs_dim; p.U = c.units; p.L = c.n_layers; p.E = c.ensemble_size;
     p.nat = (uint32_t)t->nat; p.scratch_per_member = (uint32_t)t->scratch_pm;
     p.gpart = (uint32_t)((t->nat * c.ensemble_size + 3) & ~(size_t)3);
+    p.ts = c.units > CEM_TS ? CEM_TWIDE : CEM_TS;
     p.beta1 = c.beta1; p.beta2 = c.beta2; p.eps = c.epsilon; p.clip = c.clipvalue;
     p.stamps = (long long *)(t->ws + t->oT);
 }
@@ -1242,7 +1263,7 @@ int cem_trainer_create(const cem_train_config_t *cfg, void *workspace, size_t wo
     }
     {   // the tile kernel keeps every layer's activations in LDS: (n_layers + 5) x 8 KB, beyond 48 KB only with the runtime's leave
         const size_t lds = (size_t)(cfg->n_layers + 5) * CEM_TT_NB * CEM_TT_BLK;
-        t->tile_kernel = cfg->n_layers <= CEM_TT_MAXL && std::getenv("CEM_TRAIN_GEMM_KERNEL") == nullptr;
+        t->tile_kernel = cfg->n_layers <= CEM_TT_MAXL && cfg->units <= CEM_U && std::getenv("CEM_TRAIN_GEMM_KERNEL") == nullptr;   // the tile kernel is 8 blocks wide
         hipError_t e = hipSuccess;
         if (t->tile_kernel) switch (cfg->n_layers) {
 #define CEM_CASE(LL) case LL: e = tile_kernel_lds<LL>(lds); break;

@@ -1,0 +1,265 @@
+// cem_rollout_wide.h — the rollout for hidden layers wider than the fast kernel's 128 units (128 < units <= 256; obs+act <= 128).
+//
+// The reference takes any `units` from config/models.yaml:11 (only 128 ships).  cem_rollout_tile keeps a layer's 8 feature blocks
+// in registers and streams pre-packed weights through a ring sized for exactly that; this kernel trades that speed for width:
+// the same tile (16 rows of one member for the whole horizon, 4 waves), the same arithmetic per element, the same Philox keys,
+// the same epilogue and scorer terms — but runtime loops over 16-feature blocks, activations exchanged through LDS at every
+// stage, and weights read straight from the member's NATURAL blob (cem_mpc.h layout) with per-lane buffer addressing, as
+// cem_train_tile.h reads them.  A layer's products are summed over k blocks in ascending order (the fast kernel visits a wave's
+// own blocks first): the two kernels agree to fp32 rounding, not bit for bit — which kernel runs depends on `units` alone, so
+// shard / tile-plan invariance holds within either.  One instantiation serves planning, explicit noise tensors and the
+// trajectory / head-moment outputs of cem_unfold_sequences (null pointers switch them off).
+#pragma once
+#include "cem_device.h"
+
+#define CEM_WIDE_U 256                       // widest hidden layer
+#define CEM_WIDE_NB (CEM_WIDE_U / 16)        // 16 feature blocks
+#define CEM_WIDE_OB 4                        // hidden output blocks per wave (w, w + 4, w + 8, w + 12)
+#define CEM_WIDE_SMEM (2 * CEM_WIDE_NB * 1024 + CEM_PART_FLOATS * 4)
+
+struct WideParams {
+    RolloutParams r;                         // tiles, tables, actions, noise, outputs, scorer: as for the fast kernel (wpack / bias_* unused)
+    const float *wnat;                       // [E][nat] natural weight blobs
+    uint32_t nat;                            // floats per member
+    int32_t U;
+};
+
+// A operand of one (k block, output block) pair: lane (q, j), MFMA step r holds W[(16 kb + 4 q + r)][16 ob + j] of a row-major
+// [K][ld] matrix behind `rsrc` (exactly its words: a row past K reads 0); lanes whose column is past the width read 0.
+__device__ __forceinline__ f4 cem_wide_a(const __amdgpu_buffer_rsrc_t rsrc, const int lane_off, const int kb, const int ld4)
+{
+    f4 a;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_off, (16 * kb + r) * ld4, 0));
+    return a;
+}
+
+__global__ __launch_bounds__(256) void cem_rollout_wide_kernel(const WideParams wp)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const RolloutParams &p = wp.r;
+    if (p.check_done && p.ctrl->done) return;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const TileDesc td = p.tiles[blockIdx.x];
+    const int O = p.O, A = p.A, H = p.H, U = wp.U, L = p.L, D = O + A;
+    const int nbU = (U + 15) >> 4, nbIn = p.KB_in, nbO = p.KB_obs;
+    constexpr int XB = CEM_WIDE_NB * 1024;
+    float *part = reinterpret_cast<float *>(smem + 2 * XB);
+    int xw = 0;                                            // LDS buffer the current stage's outputs go to
+    const PhiloxKey key = cem_key(p.ctrl);
+    const float *Wm = wp.wnat + (size_t)__builtin_amdgcn_readfirstlane(td.member) * wp.nat;
+    // natural-blob offsets (cem_mpc.h): W_0,b_0,...,W_mu,b_mu,W_var,b_var
+    auto offW = [&](int l) { return l == 0 ? (size_t)0 : (size_t)D * U + U + (size_t)(l - 1) * ((size_t)U * U + U); };
+    auto offb = [&](int l) { return offW(l) + (size_t)(l == 0 ? D : U) * U; };
+    const size_t oWmu = (size_t)D * U + U + (size_t)(L - 1) * ((size_t)U * U + U), obmu = oWmu + (size_t)U * O;
+    const size_t oWv = obmu + O, obv = oWv + (size_t)U * O;
+    auto rsrc_of = [&](const float *base, int words) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, words * 4, 0x00020000);
+    };
+
+    // ---- state registers: wave w owns input feature blocks Fo = w + 4 i (i < 2: obs+act <= 128) ---------------------
+    const int slot0 = j < td.cnt ? j : td.cnt - 1;
+    f4 s[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f0 = 16 * (w + 4 * i) + 4 * q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = f0 + r;
+            float v = 0.f;
+            if (f < O) v = td.s0_base < 0 ? p.ctrl->state[f] : p.s0[(size_t)(td.s0_base + slot0) * O + f];
+            s[i][r] = v;
+        }
+    }
+    const float *actrow = p.actions + (size_t)(td.act_base + slot0) * H * A;
+
+    float d_prev = 0.f, c_prev = 0.f, cum = 0.f;
+    bool done = false;
+    const int nk = 1 + p.sc.n_cost;
+    // reward / cost / done bookkeeping of step T_ (wave 0): the same statements as cem_rollout_tile's CEM_BOOKKEEP
+#define CEM_WIDE_BOOKKEEP(T_) do { if (w == 0) { \
+        float dn = fminf(fminf(part[0 * 64 + lane], part[1 * 64 + lane]), fminf(part[2 * 64 + lane], part[3 * 64 + lane])); \
+        float cn = 0.f; \
+        for (int k = 1; k < nk; ++k) { \
+            const float dk = fminf(fminf(part[(k * 4 + 0) * 64 + lane], part[(k * 4 + 1) * 64 + lane]), \
+                                   fminf(part[(k * 4 + 2) * 64 + lane], part[(k * 4 + 3) * 64 + lane])); \
+            cn = cn + ((dk <= p.sc.cost_size[k - 1]) ? 1.0f : 0.0f); } \
+        if (p.sc.indicator) cn = cn > 0.f ? 1.0f : 0.0f; \
+        if ((T_) >= 0) { \
+            const bool ga = d_prev <= p.sc.goal_thresh; \
+            float r = (d_prev - dn) * p.sc.reward_distance + (ga ? 1.0f : 0.0f) * p.sc.reward_goal; \
+            if (p.sc.reward_clip > 0.f) r = fminf(fmaxf(r, -p.sc.reward_clip), p.sc.reward_clip); \
+            if (p.variant == 1) { \
+                done = done || ga; \
+                const float nd = done ? 0.0f : 1.0f; \
+                const float cst = c_prev * nd; \
+                if (p.costs && lane < td.cnt) p.costs[(size_t)(T_) * p.Bloc + td.row_base + lane] = (uint8_t)cst; \
+                cum = cum + r * nd; \
+            } else { \
+                const float nd = done ? 0.0f : 1.0f; \
+                cum = cum + r * nd; \
+                done = done || ga; \
+            } } \
+        d_prev = dn; c_prev = cn; } } while (0)
+
+    for (int t = -1; t < H; ++t) {
+        if (t >= 0) {
+            __syncthreads();                               // the previous step's next-input blocks and scorer terms are in LDS
+            CEM_WIDE_BOOKKEEP(t - 1);
+            // ---- dense layers: h = relu(h W + b)  (mlp_ensemble.py:18-22): wave w computes output blocks w, w + 4, w + 8, w + 12 ----
+            for (int l = 0; l < L; ++l) {
+                const int in = l == 0 ? D : U, nbK = l == 0 ? nbIn : nbU;
+                const __amdgpu_buffer_rsrc_t rs = rsrc_of(Wm + offW(l), in * U);
+                const float *bl = Wm + offb(l);
+                f4 acc[CEM_WIDE_OB];
+                int loff[CEM_WIDE_OB];
+#pragma unroll
+                for (int i = 0; i < CEM_WIDE_OB; ++i) {
+                    const int n = 16 * (w + 4 * i) + j;                              // this lane's output column as the A operand
+                    loff[i] = n < U ? (4 * q * U + n) * 4 : 0x7fffff00;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const int o = 16 * (w + 4 * i) + 4 * q + r; acc[i][r] = o < U ? bl[o] : 0.f; }
+                }
+                const char *xin = smem + (xw ^ XB);
+                f4 a_nxt[CEM_WIDE_OB];
+#pragma unroll
+                for (int i = 0; i < CEM_WIDE_OB; ++i) a_nxt[i] = cem_wide_a(rs, loff[i], 0, U * 4);
+                for (int kb = 0; kb < nbK; ++kb) {
+                    f4 a_cur[CEM_WIDE_OB];
+#pragma unroll
+                    for (int i = 0; i < CEM_WIDE_OB; ++i) a_cur[i] = a_nxt[i];
+                    if (kb + 1 < nbK) {                                               // the next k block's weights, a block ahead
+#pragma unroll
+                        for (int i = 0; i < CEM_WIDE_OB; ++i) a_nxt[i] = cem_wide_a(rs, loff[i], kb + 1, U * 4);
+                    }
+                    const f4 hb = *reinterpret_cast<const f4 *>(xin + (kb * 64 + lane) * 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int i = 0; i < CEM_WIDE_OB; ++i) acc[i] = CEM_MFMA(a_cur[i][r], hb[r], acc[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < CEM_WIDE_OB; ++i) {
+                    const int ob = w + 4 * i;
+                    if (ob < nbU) {                                                   // wave-uniform
+                        f4 h = acc[i];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h[r] = (16 * ob + 4 * q + r < U) ? fmaxf(h[r], 0.f) : 0.f;
+                        *reinterpret_cast<f4 *>(smem + xw + (ob * 64 + lane) * 16) = h;
+                    }
+                }
+                xw ^= XB;
+                __syncthreads();
+            }
+        }
+        // ---- heads (mlp_ensemble.py:33-34,189-193), state update (transition_model.py:75), scorer terms (safety_gym.py:188-192)
+        //      and the next scaled input (transition_model.py:70-72,79-87): cem_rollout_tile's epilogue, block by block ----
+        float pm[CEM_NKIND];
+#pragma unroll
+        for (int k = 0; k < CEM_NKIND; ++k) pm[k] = __builtin_inff();
+        const int tn = (t + 1 < H) ? t + 1 : H - 1;
+        const float live = (t >= 0) ? 1.0f : 0.0f;
+        const float sampling = p.sampling ? 1.0f : 0.0f;
+        const float goalm = p.sc.goal_mode ? 1.0f : 0.0f;
+        const char *hL = smem + (xw ^ XB);                 // the last hidden layer's output
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int Fo = w + 4 * i;
+            if (Fo >= nbIn) continue;                      // wave-uniform: no such input block
+            const int f0 = 16 * Fo + 4 * q;
+            const f4 mn4 = *reinterpret_cast<const f4 *>(p.nmin + f0);
+            const f4 rd4 = *reinterpret_cast<const f4 *>(p.nrdelta + f0);
+            const f4 om4 = *reinterpret_cast<const f4 *>(p.omask + f0) * live;
+            const f4 isact4 = *reinterpret_cast<const f4 *>(p.omask + CEM_U + f0);
+            const f4 sel0 = *reinterpret_cast<const f4 *>(p.kind_sel + f0);
+            const f4 sel1 = *reinterpret_cast<const f4 *>(p.kind_sel + CEM_U + f0);
+            f4 act4, eps4, accm, accv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int af = f0 + r - O; af = af < 0 ? 0 : (af >= A ? A - 1 : af);
+                act4[r] = actrow[tn * A + af];
+                const int fc = (f0 + r < O) ? f0 + r : O - 1;
+                accm[r] = (f0 + r < O) ? Wm[obmu + fc] : 0.f;
+                accv[r] = (f0 + r < O) ? Wm[obv + fc] : 0.f;
+            }
+            if (p.eps_model) {
+                const int tc = t < 0 ? 0 : t;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int fc = (f0 + r < O) ? f0 + r : O - 1;
+                    eps4[r] = p.eps_model[((size_t)tc * p.Btot + td.noise_row_base + slot0) * O + fc];
+                }
+            } else {
+                eps4 = cem_normal4((uint32_t)(td.noise_row_base + slot0), (uint32_t)t, (uint32_t)p.it, (uint32_t)(4 * Fo + q), CEM_STREAM_MODEL, key);
+            }
+            eps4 = eps4 * sampling;
+            if (t >= 0 && Fo < nbO) {                      // wave-uniform: mean and variance heads of observation block Fo
+                const __amdgpu_buffer_rsrc_t rm = rsrc_of(Wm + oWmu, U * O), rv = rsrc_of(Wm + oWv, U * O);
+                const int n = 16 * Fo + j;
+                const int lo = n < O ? (4 * q * O + n) * 4 : 0x7fffff00;
+                f4 am = cem_wide_a(rm, lo, 0, O * 4), av = cem_wide_a(rv, lo, 0, O * 4);
+                for (int kb = 0; kb < nbU; ++kb) {
+                    const f4 cm = am, cv = av;
+                    if (kb + 1 < nbU) { am = cem_wide_a(rm, lo, kb + 1, O * 4); av = cem_wide_a(rv, lo, kb + 1, O * 4); }
+                    const f4 hb = *reinterpret_cast<const f4 *>(hL + (kb * 64 + lane) * 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { accm = CEM_MFMA(cm[r], hb[r], accm); accv = CEM_MFMA(cv[r], hb[r], accv); }
+                }
+            }
+            f4 sn = s[i], x;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float mu = accm[r];
+                const float sd = __builtin_amdgcn_sqrtf(cem_softplus(accv[r]) + 1e-4f);
+                const float d = mu + sd * eps4[r];                                   // Normal.sample = loc + scale * eps
+                sn[r] = sn[r] + d * om4[r];                                          // s_t += d_s_t on observation features
+                if (t >= 0 && j < td.cnt && f0 + r < O) {
+                    const size_t o = ((size_t)(td.row_base + j) * H + t) * O + f0 + r;
+                    if (p.mu_out) p.mu_out[o] = mu;
+                    if (p.sd_out) p.sd_out[o] = sd;
+                }
+                const float lid = fminf(fmaxf(p.sc.D - p.sc.D * (1.0f - sn[r]), 0.f), p.sc.D);
+                const float gv = goalm != 0.f ? fmaxf(sn[r], 0.f) : lid;
+                pm[0] = fminf(pm[0], fmaxf(gv, sel0[r]));
+                pm[1] = fminf(pm[1], fmaxf(lid, sel1[r]));
+                const float xv = __builtin_fmaf(isact4[r], act4[r], sn[r]);          // s is 0 off the observation features
+                x[r] = (xv - mn4[r]) * rd4[r];
+            }
+            s[i] = sn;
+            if (p.traj && j < td.cnt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (f0 + r < O) p.traj[((size_t)(td.row_base + j) * (H + 1) + (t + 1)) * O + f0 + r] = sn[r];
+            }
+            *reinterpret_cast<f4 *>(smem + xw + (Fo * 64 + lane) * 16) = x;
+            for (int k = 2; k < nk; ++k) {                 // cost kinds beyond the first
+                const f4 selk = *reinterpret_cast<const f4 *>(p.kind_sel + k * CEM_U + f0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float lid = fminf(fmaxf(p.sc.D - p.sc.D * (1.0f - sn[r]), 0.f), p.sc.D);
+                    pm[k] = fminf(pm[k], fmaxf(lid, selk[r]));
+                }
+            }
+        }
+        // min over the 4 lane rows holding different features of the same batch row, then this wave's term per row
+#pragma unroll
+        for (int k = 0; k < CEM_NKIND; ++k) {
+            if (k < 2 || k < nk) {
+                const uint32_t mb = __float_as_uint(pm[k]);
+                const auto r16 = __builtin_amdgcn_permlane16_swap(mb, mb, false, false);
+                const float m16 = fminf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+                const uint32_t m16b = __float_as_uint(m16);
+                const auto r32 = __builtin_amdgcn_permlane32_swap(m16b, m16b, false, false);
+                part[(k * 4 + w) * 64 + j] = fminf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+            }
+        }
+        xw ^= XB;
+    }
+    __syncthreads();
+    CEM_WIDE_BOOKKEEP(H - 1);
+    if (w == 0 && lane < td.cnt) p.ret[td.row_base + lane] = cum;
+}
+#undef CEM_WIDE_BOOKKEEP

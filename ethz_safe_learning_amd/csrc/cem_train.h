@@ -18,7 +18,8 @@
 
 #define CEM_TB 64            // max minibatch rows per member (config/models.yaml:4 batch_size: 64)
 #define CEM_TROWS 16         // minibatch rows per workgroup
-#define CEM_TS 128           // row stride of every activation matrix in the scratch (inputs_dim, outputs_dim, units <= 128)
+#define CEM_TS 128           // row stride of every activation matrix in the scratch for units <= 128 (TrainParams::ts: 256 above)
+#define CEM_TWIDE 256         // widest hidden layer the GEMM-by-GEMM kernel is laid out for (inputs_dim, outputs_dim <= 128)
 #define CEM_TPARTS (CEM_TB / CEM_TROWS)
 
 struct TrainParams {
@@ -33,6 +34,7 @@ struct TrainParams {
     int32_t chunk;               // chunk = the minibatch; validation: every 64-row slice of the set in ONE launch, loss_part per chunk)
     int32_t D, O, U, L, E;
     uint32_t nat, scratch_per_member, gpart;
+    int32_t ts;                  // row stride of the GEMM kernel's activation matrices in the scratch: CEM_TS, or CEM_TWIDE for units > 128
     float lr_t, beta1, beta2, eps, clip;
     float *loss_out;             // train: [E] loss share of each member; eval: [E][2] raw sums (log term, squared term)
     int32_t train;
@@ -418,8 +420,8 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
     if (Bt <= 0) return;                          // a short minibatch: the Adam kernel only adds the parts that exist
     float *W = p.W + (size_t)m * p.nat, *G = p.grad + (size_t)part * p.gpart + (size_t)m * p.nat;
     float *sc = p.scratch + (size_t)blockIdx.x * p.scratch_per_member;
-    // scratch carve: every activation matrix has row stride S = CEM_TS (D, O, U <= 128; units below 128 leave columns unused)
-    constexpr int S = CEM_TS;
+    // scratch carve: every activation matrix has row stride S (128: D, O, U <= 128, narrower units leave columns unused; 256 for wider units)
+    const int S = p.ts;
     float *xs = sc;                              // [TROWS][S]   h_0
     float *hs = xs + CEM_TROWS * S;              // [L][TROWS][S] h_1..h_L
     float *mu = hs + (size_t)L * CEM_TROWS * S;  // [TROWS][S]

@@ -36,7 +36,7 @@ extern "C" {
 enum cem_status {
     CEM_OK = 0,
     CEM_ERR_INVALID_ARG = 1,     /* NULL pointer / bad dims */
-    CEM_ERR_UNSUPPORTED = 2,     /* e.g. units > 128, task 'push', obs+act > 128 */
+    CEM_ERR_UNSUPPORTED = 2,     /* e.g. units > 256, task 'push', obs+act > 128 */
     CEM_ERR_SPLIT = 3,           /* (particles*n_samples) % ensemble_size != 0: tf.split would raise (mlp_ensemble.py:123) */
     CEM_ERR_WORKSPACE = 4,       /* workspace too small / misaligned */
     CEM_ERR_HIP = 5,             /* a HIP runtime call failed; cem_last_hip_error() has the code */
@@ -76,8 +76,9 @@ typedef struct cem_scorer {
 typedef struct cem_config {
     int32_t abi_version;          /* CEM_ABI_VERSION */
     int32_t obs_dim, act_dim;
-    int32_t units, n_layers;      /* mlp_params: any units <= 128 (narrower layers run zero-padded to the 128-wide kernel: the result is
-                                   * that of the narrow network exactly, the padding adds zeros) */
+    int32_t units, n_layers;      /* mlp_params: units <= 128 run on the fast kernels (narrower layers zero-padded to the 128-wide form:
+                                   * exactly the narrow network's result); 129..256 on width-generic kernels (same semantics, the natural
+                                   * weight blob read in place; a functional path, not a tuned one) */
     int32_t ensemble_size;        /* E */
     int32_t particles;            /* P */
     int32_t n_samples;            /* N (global, over all ranks) */

@@ -46,7 +46,7 @@ def test_config_struct_matches_header_size(built_lib):
 
 
 @pytest.mark.parametrize('kw,status', [
-    (dict(units=192), 2),                                # units <= 128 in this build (narrower ones are zero-padded)
+    (dict(units=300), 2),                                # units <= 256 (<= 128: the fast kernel, zero-padded; above: the wide kernel)
     (dict(units=0), 1),
     (dict(obs_dim=120, act_dim=12, act_low=[-1] * 12, act_high=[1] * 12), 2),                 # obs+act > 128
     (dict(particles=3, n_samples=7, n_elite=2, ensemble_size=5), 3),   # tf.split would raise (mlp_ensemble.py:123)

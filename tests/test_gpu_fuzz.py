@@ -30,7 +30,7 @@ def _random_rollout_case(seed):
         P = int(rng.integers(1, 5))                        # members split particles: P * N must divide by E
         N = E * int(rng.integers(1, 40))
     return dict(O=O, A=A, E=E, P=P, N=N, H=int(rng.integers(1, 11)), L=int(rng.integers(1, 6)),
-                units=int(rng.choice([16, 17, 33, 64, 100, 127, 128])), variant=str(rng.choice(['cem', 'safe'])),
+                units=int(rng.choice([16, 17, 33, 64, 100, 127, 128, 129, 160, 200, 256])), variant=str(rng.choice(['cem', 'safe'])),
                 rc=int(rng.integers(0, 5)), seg=int(rng.choice([0, 0, 1, 2, 3])), sampling=bool(rng.random() < 0.8),
                 scale=bool(rng.random() < 0.8), post=float(rng.choice([0.15, 0.3, 0.5])))
 
@@ -62,7 +62,7 @@ def _random_training_case(seed):
     O = int(rng.choice([3, 6, 17, 28, 60, 61, 100, 120]))
     A = int(rng.integers(1, 8))
     return dict(E=int(rng.integers(1, 6)), D=min(O + A, 128), O=O, L=int(rng.integers(1, 8)), bt=int(rng.integers(1, 65)),
-                units=int(rng.choice([8, 17, 31, 48, 64, 99, 128])), kernel=str(rng.choice(['tile', 'gemm'])))
+                units=int(rng.choice([8, 17, 31, 48, 64, 99, 128, 144, 201, 256])), kernel=str(rng.choice(['tile', 'gemm'])))
 
 
 @pytest.mark.parametrize('seed', range(16 * SCALE))
@@ -84,6 +84,8 @@ def test_random_shape_training_steps(seed, monkeypatch):
     tr.set_state(pb['weights'])
     w64 = o.cast_weights(pb['weights'], np.float64)
     ms64, vs64 = o.zeros_like_weights(w64), o.zeros_like_weights(w64)
+    w32 = o.cast_weights(pb['weights'], np.float32)                       # how far fp32 arithmetic itself drifts from fp64 on this case
+    ms32, vs32 = o.zeros_like_weights(w32), o.zeros_like_weights(w32)
     x_dev, y_dev = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()
     lr = 0.00025
     for t in range(1, 4):
@@ -95,13 +97,18 @@ def test_random_shape_training_steps(seed, monkeypatch):
         tr.synchronize()
         idx = perm[:, off:off + bt]
         ref = o.training_step(w64, ms64, vs64, X[idx].astype(np.float64), Y[idx].astype(np.float64), lr, t)
+        o.training_step(w32, ms32, vs32, X[idx], Y[idx], np.float32(lr), t)
         got = float(loss_dev.sum().item())
         assert abs(got - ref) <= 1e-5 * max(1.0, abs(ref)), (c, t, got, ref)
-    worst = 0.0
-    for a, b in zip(tr.get_weights(), w64):
-        for ka, kb in zip(o._flat_params(a), o._flat_params(b)):
-            worst = max(worst, float(np.abs(ka - kb).max()))
-    assert worst <= 2e-5, (c, worst)
+
+    def worst_of(wa, wb):
+        return max(float(np.abs(ka - kb).max()) for a, b in zip(wa, wb) for ka, kb in zip(o._flat_params(a), o._flat_params(b)))
+    # Adam's first steps move every weight by ~lr whatever the gradient's size, so a gradient of ~1e-12 turns rounding into the
+    # SIGN of an update: where the numpy fp32 oracle itself drifts from fp64 (deep, wide nets), the same allowance applies
+    # (and the GPU's summation order can flip one the numpy order does not: 1 case in 4 400 landed at 2.2e-5).  A wrong gradient
+    # moves weights by ~lr per step = 7.5e-4 over these three steps, so 6e-5 still separates rounding from a bug by a decade.
+    worst, drift32 = worst_of(tr.get_weights(), w64), worst_of(w32, w64)
+    assert worst <= max(6e-5, 3.0 * drift32), (c, worst, drift32)
     vl = tr.validation_loss(x_dev[:77], y_dev[:77])
     ref_vl = o.validation_loss(w64, X[:77].astype(np.float64), Y[:77].astype(np.float64))
     assert abs(vl - ref_vl) <= 2e-5 * max(1.0, abs(ref_vl)), (c, vl, ref_vl)
@@ -119,7 +126,7 @@ def _random_plan_case(seed):
     return dict(O=O, A=A, E=E, P=P, N=N, k=min(k, N), H=int(rng.integers(1, 9)), I=int(rng.integers(2, 5)),
                 variant=str(rng.choice(['cem', 'safe'])), smoothing=float(rng.choice([0.0, 0.1, 0.5])),
                 thr=float(rng.choice([-1.0, -1.0, 0.3, 0.6])), noise=float(rng.choice([0.0, 0.05])),
-                select_mode=int(rng.choice([0, 1, 2])), use_graph=False)
+                select_mode=int(rng.choice([0, 1, 2])), use_graph=False, units=int(rng.choice([64, 64, 192])))
 
 
 @pytest.mark.parametrize('seed', range(24 * SCALE))
@@ -130,7 +137,7 @@ def test_random_shape_whole_plan_teacher_forced(seed):
     import torch
     c = _random_plan_case(seed)
     O, A, E, P, N, H, I, k = c['O'], c['A'], c['E'], c['P'], c['N'], c['H'], c['I'], c['k']
-    pb = hp.make_problem(O, A, E, 2, seed=400 + seed, units=64)
+    pb = hp.make_problem(O, A, E, 2, seed=400 + seed, units=c['units'])
     ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, variant=c['variant'], post=0.3, smoothing=c['smoothing'], thr=c['thr'],
                             noise=c['noise'], select_mode=c['select_mode'])
     pl = hp.make_planner(pb, pcfg)
@@ -182,7 +189,8 @@ def _random_shard_case(seed):
     A = int(rng.integers(1, 4))
     O = int(rng.choice([9, 40, 60, 100]))
     return dict(W=W, E=E, P=P, N=N, O=O, A=A, H=int(rng.integers(1, 9)), variant=str(rng.choice(['cem', 'safe'])),
-                rc_full=int(rng.integers(0, 5)), rc_shard=int(rng.integers(0, 5)), seg=int(rng.choice([0, 1, 2, 3])))
+                rc_full=int(rng.integers(0, 5)), rc_shard=int(rng.integers(0, 5)), seg=int(rng.choice([0, 1, 2, 3])),
+                units=int(rng.choice([96, 96, 176])))
 
 
 @pytest.mark.parametrize('seed', range(16 * SCALE))
@@ -193,7 +201,7 @@ def test_random_shape_shard_and_tile_invariance(seed):
     import torch
     c = _random_shard_case(seed)
     W, E, P, N, O, A, H = c['W'], c['E'], c['P'], c['N'], c['O'], c['A'], c['H']
-    pb = hp.make_problem(O, A, E, 3, seed=500 + seed, units=96)
+    pb = hp.make_problem(O, A, E, 3, seed=500 + seed, units=c['units'])
 
     def run(world, rank, rc, seg):
         _, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=max(1, N // 10), I=1, variant=c['variant'], post=0.3, world_size=world, rank=rank,
@@ -225,7 +233,7 @@ def _random_unfold_case(seed):
     O = min(int(rng.choice([3, 6, 20, 47, 60, 64, 65, 100, 120])), 128 - A)
     E = int(rng.integers(1, 7))
     return dict(O=O, A=A, E=E, L=int(rng.integers(1, 6)), B=E * int(rng.integers(1, 70)), H=int(rng.integers(1, 8)),
-                units=int(rng.choice([16, 40, 64, 101, 128])), sampling=bool(rng.random() < 0.7), scale=bool(rng.random() < 0.7),
+                units=int(rng.choice([16, 40, 64, 101, 128, 130, 224, 256])), sampling=bool(rng.random() < 0.7), scale=bool(rng.random() < 0.7),
                 variant=str(rng.choice(['cem', 'safe'])))
 
 

@@ -383,6 +383,52 @@ def test_full_plan_matches_oracle(variant):
     print('%s plan: elite sets matched in every iteration: %s' % (variant, elites_match))
 
 
+@pytest.mark.parametrize('variant,units', [('cem', 256), ('safe', 160)])
+def test_wide_units_plan_matches_oracle(variant, units):
+    """Hidden layers wider than 128 units (cem_rollout_wide_kernel on the natural weight blob): a whole plan against the oracle
+    on identical noise tensors — scores per iteration, elite sets, mu / sigma, the returned action — and the Philox plan against
+    the same plan on its dumped noise, eagerly and as a captured graph."""
+    torch = _torch()
+    pb = hp.make_problem(seed=52, units=units)
+    N, H, P, E, k, I = 120, 8, 5, 5, 12, 3
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, variant=variant, noise=0.01, post=0.3)
+    pl = hp.make_planner(pb, pcfg)
+    ea, em, eo = hp.noise(I, N, H, 2, P, 60, seed=13)
+    trace = []
+    ra, rs, rit = o.do_generate_action(pb['state'], pb['weights'], pb['inputs_min'], pb['inputs_max'], pb['low'], pb['high'],
+                                       ea, em, eo, ocfg, pb['scorer'], trace=trace)
+    pl.plan_begin(pb['state'], eps_act=ea, eps_model=em)
+    for it in range(I):
+        pl.plan_rollout(it)
+        torch.cuda.synchronize()
+        scores = pl.scores_local().cpu().numpy().copy()
+        bad = np.abs(scores - trace[it]['scores']) > FULL_SIZE_ATOL
+        assert bad.mean() < 0.05, 'iteration %d: %d/%d scores differ' % (it, bad.sum(), N)
+        pl.plan_select(it)
+        torch.cuda.synchronize()
+        assert set(pl.elite_idx().cpu().numpy().tolist()) == set(trace[it]['elite'].tolist())
+        ms = pl.mu_sigma().cpu().numpy()
+        np.testing.assert_allclose(ms[0], trace[it]['mu'], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(ms[1], trace[it]['sigma'], rtol=1e-5, atol=1e-6)
+    a, s, it = pl.plan_end(eps_out=eo)
+    assert it == rit == I
+    np.testing.assert_allclose(a, ra, rtol=1e-5, atol=1e-7)
+    assert abs(s - rs) <= FULL_SIZE_ATOL
+    # Philox == dumped noise; graph == eager
+    fa, fm, fo = pl.fill_noise(seed=5, call=9)
+    a1, s1, i1 = pl.plan(pb['state'], seed=5, call=9)
+    a2, s2, i2 = pl.plan(pb['state'], eps_act=fa, eps_model=fm, eps_out=fo.cpu().numpy())
+    np.testing.assert_array_equal(a1, a2)
+    assert s1 == s2
+    _, gcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, variant=variant, noise=0.01, post=0.3, use_graph=True)
+    pg = hp.make_planner(pb, gcfg)
+    for rep in range(3):
+        ag, sg, ig = pg.plan(pb['state'], seed=5, call=9)
+    assert pg.graph_status() == 'graph'
+    np.testing.assert_array_equal(ag, a1)
+    assert sg == s1
+
+
 def test_plan_philox_equals_plan_on_dumped_noise_and_graph():
     torch = _torch()
     pb = hp.make_problem(seed=61)

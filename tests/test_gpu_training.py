@@ -25,7 +25,8 @@ def _setup(E=3, D=62, O=60, L=4, seed=0, units=128):
 # narrow units; one layer with units % 4 != 0; six layers (the deepest tile-kernel instantiation); seven layers (beyond it: the
 # GEMM kernel whatever is asked); a minibatch shorter than one 16-row part
 SHAPES = [(3, 62, 60, 4, 64, 128), (2, 8, 6, 2, 37, 128), (2, 112, 100, 3, 64, 128), (2, 62, 60, 3, 50, 48), (2, 20, 17, 1, 64, 17),
-          (1, 62, 60, 6, 64, 100), (1, 30, 28, 7, 20, 64), (2, 62, 60, 4, 9, 128)]
+          (1, 62, 60, 6, 64, 100), (1, 30, 28, 7, 20, 64), (2, 62, 60, 4, 9, 128),
+          (2, 62, 60, 3, 64, 256), (1, 40, 37, 2, 33, 160)]      # wider than 128 units: the GEMM kernel at row stride 256, whatever is asked
 
 
 @pytest.mark.parametrize('kernel', ['tile', 'gemm'])
