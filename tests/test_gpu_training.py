@@ -77,12 +77,13 @@ def test_training_steps_match_oracle(E, D, O, L, bt, units, kernel, monkeypatch)
     assert abs(vl - ref_vl) <= 1e-5 * max(1.0, abs(ref_vl))
 
 
-def test_fit_learns_and_feeds_the_planner():
+@pytest.mark.parametrize('units', [128, 192])
+def test_fit_learns_and_feeds_the_planner(units):
     """TransitionModel.fit -> MlpEnsemble.fit (reference loop) on a learnable synthetic transition function, then the
-    planner picks the new weights up through model.version."""
+    planner picks the new weights up through model.version.  192 units: the width-generic kernels end to end."""
     from tests.test_simba_api import make_agent_parts
     np.random.seed(0)
-    env, model, pol = make_agent_parts('cem_mpc', seed=1)
+    env, model, pol = make_agent_parts('cem_mpc', seed=1, units=units)
     model.model.training_steps = 300
     model.model.train_epochs = 10
     rng = np.random.default_rng(0)

@@ -21,10 +21,12 @@ MODELS_YAML = dict(ensemble_size=15, batch_size=64, validation_split=0.2, learni
                    training_steps=5000, mlp_params=dict(n_layers=4, units=128, activation='tf.nn.relu', dropout_rate=0.0))
 
 
-def make_agent_parts(policy_name, seed=0):
+def make_agent_parts(policy_name, seed=0, units=None):
     """What MbrlAgent.__init__ does (mbrl_agent.py:27-35,103-118; agent_factory.py:22 injects train_epochs)."""
     env = SyntheticSafetyGym()
     model_params = dict(MODELS_YAML, scale_features=True, train_epochs=10, seed=seed)
+    if units is not None:                                  # models.yaml:11 takes any width
+        model_params['mlp_params'] = dict(MODELS_YAML['mlp_params'], units=units)
     model = TransitionModel(model='mlp_ensemble', observation_space=env.observation_space, action_space=env.action_space,
                             sampling_propagation=True, **model_params)
     policy_params = dict(POLICIES_YAML[policy_name])
