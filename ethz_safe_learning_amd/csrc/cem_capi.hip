@@ -141,6 +141,36 @@ void pack_member(const Dims &d, const float *nat, float *out)
     }
 }
 
+// Weight image of one member for cem_rollout_wide_kernel: 1 KB groups [64 lanes][4] in cem_wide_base / cem_wide_groups order;
+// lane (q, j), word r of group (k block kb, output block ob) = W[16 kb + 4 q + r][16 ob + j], zero past the matrix.
+size_t wide_image_floats(const Dims &d) { return (size_t)cem_wide_groups(d.L, d.KB_in, (d.U + 15) / 16, d.KB_obs) * 256; }
+void pack_member_wide(const Dims &d, const float *nat, float *out)
+{
+    const NatOff no = nat_offsets(d);
+    const int nbU = (d.U + 15) / 16, nbIn = d.KB_in, nbO = d.KB_obs;
+    auto emit = [&](const float *W, int in_dim, int out_dim, int g, int kb, int ob) {
+        float *dst = out + (size_t)g * 256;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int q = lane >> 4, j = lane & 15;
+            for (int r = 0; r < 4; ++r) {
+                const int k = 16 * kb + 4 * q + r, o = 16 * ob + j;
+                dst[lane * 4 + r] = (k < in_dim && o < out_dim) ? W[(size_t)k * out_dim + o] : 0.f;
+            }
+        }
+    };
+    for (int l = 0; l < d.L; ++l) {
+        const int in = l == 0 ? d.Din : d.U, nbK = l == 0 ? nbIn : nbU, gl = cem_wide_base(l, nbIn, nbU);
+        for (int kb = 0; kb < nbK; ++kb)
+            for (int ob = 0; ob < nbU; ++ob) emit(nat + no.W[l], in, d.U, gl + kb * nbU + ob, kb, ob);
+    }
+    const int gh = cem_wide_base(d.L, nbIn, nbU);
+    for (int kb = 0; kb < nbU; ++kb)
+        for (int ob = 0; ob < nbO; ++ob) {
+            emit(nat + no.Wmu, d.U, d.O, gh + kb * nbO + ob, kb, ob);
+            emit(nat + no.Wvar, d.U, d.O, gh + nbU * nbO + kb * nbO + ob, kb, ob);
+        }
+}
+
 struct Tile6 { int32_t v[6]; };
 
 // tiles of one particle-major row space.  Rows r = p*nstride + n (n in [n_lo, n_hi)) use member
@@ -319,7 +349,7 @@ Layout make_layout(const cem_config_t *c, const Dims &d, size_t max_tiles)
     l.returns = take((size_t)d.Bloc * 4);
     l.costs = take((size_t)d.H * d.Bloc);
     l.result = take(64 * 4);
-    l.wpack = take(d.wide ? (size_t)d.E * d.nat_member_floats * 4 : (size_t)d.E * d.member_stride_f4 * 16);   // wide: the natural blob itself
+    l.wpack = take(d.wide ? (size_t)d.E * (align256(d.nat_member_floats * 4) + wide_image_floats(d) * 4) : (size_t)d.E * d.member_stride_f4 * 16);   // wide: natural blobs, then the packed images
     l.bias_h = take((size_t)d.E * d.L * CEM_U * 4);
     l.bias_mu = take((size_t)d.E * CEM_U * 4);
     l.bias_var = take((size_t)d.E * CEM_U * 4);
@@ -621,8 +651,12 @@ int cem_planner_set_weights(cem_planner_t *h, const float *blob, size_t n_floats
     if (!h || !blob) return CEM_ERR_INVALID_ARG;
     const Dims &d = h->d;
     if (n_floats != d.nat_member_floats * d.E) return CEM_ERR_INVALID_ARG;
-    if (d.wide) {                                       // the wide kernel reads the natural blob as it is
+    if (d.wide) {                                       // the wide kernel: natural blobs (biases) + per-member operand-order images
+        const size_t img = wide_image_floats(d);
+        std::vector<float> images(img * d.E);
+        for (int m = 0; m < d.E; ++m) pack_member_wide(d, blob + (size_t)m * d.nat_member_floats, images.data() + (size_t)m * img);
         HIPCHK(hipMemcpyAsync(h->ws + h->lay.wpack, blob, n_floats * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->ws + h->lay.wpack + align256(n_floats * 4), images.data(), images.size() * 4, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         h->have_weights = true;
         return CEM_OK;
@@ -710,6 +744,7 @@ hipError_t launch_rollout_wide(const cem_planner *h, const RolloutParams &rp, in
 {
     WideParams wp; wp.r = rp;
     wp.wnat = (const float *)(h->ws + h->lay.wpack); wp.nat = (uint32_t)h->d.nat_member_floats; wp.U = h->d.U;
+    wp.wimg = (const f4 *)(h->ws + h->lay.wpack + align256((size_t)h->d.E * h->d.nat_member_floats * 4)); wp.img_f4 = (uint32_t)(wide_image_floats(h->d) / 4);
     hipLaunchKernelGGL(cem_rollout_wide_kernel, dim3(n_tiles), dim3(256), CEM_WIDE_SMEM, h->stream, wp);
     return hipGetLastError();
 }

@@ -4,8 +4,9 @@
 // in registers and streams pre-packed weights through a ring sized for exactly that; this kernel trades that speed for width:
 // the same tile (16 rows of one member for the whole horizon, 4 waves), the same arithmetic per element, the same Philox keys,
 // the same epilogue and scorer terms — but runtime loops over 16-feature blocks, activations exchanged through LDS at every
-// stage, and weights read straight from the member's NATURAL blob (cem_mpc.h layout) with per-lane buffer addressing, as
-// cem_train_tile.h reads them.  A layer's products are summed over k blocks in ascending order (the fast kernel visits a wave's
+// stage, and weights streamed from a per-member image packed in A-operand order — one 1 KB group per (k block, output block),
+// so a lane's four MFMA steps of a group are ONE 16-byte load (read from the natural layout they were four 4-byte loads of 64-byte
+// rows: 63 -> 77 TFLOP/s at 256 units; the biases still come from the natural blob, which travels with the image).  A layer's products are summed over k blocks in ascending order (the fast kernel visits a wave's
 // own blocks first): the two kernels agree to fp32 rounding, not bit for bit — which kernel runs depends on `units` alone, so
 // shard / tile-plan invariance holds within either.  One instantiation serves planning, explicit noise tensors and the
 // trajectory / head-moment outputs of cem_unfold_sequences (null pointers switch them off).
@@ -19,19 +20,49 @@
 
 struct WideParams {
     RolloutParams r;                         // tiles, tables, actions, noise, outputs, scorer: as for the fast kernel (wpack / bias_* unused)
-    const float *wnat;                       // [E][nat] natural weight blobs
+    const float *wnat;                       // [E][nat] natural weight blobs (the biases are read from here)
+    const f4 *wimg;                          // [E][img_f4] packed weight images: groups [64 lanes][f4], cem_wide_group_* order
     uint32_t nat;                            // floats per member
+    uint32_t img_f4;                         // f4 per member image
     int32_t U;
 };
 
-// A operand of one (k block, output block) pair: lane (q, j), MFMA step r holds W[(16 kb + 4 q + r)][16 ob + j] of a row-major
-// [K][ld] matrix behind `rsrc` (exactly its words: a row past K reads 0); lanes whose column is past the width read 0.
-__device__ __forceinline__ f4 cem_wide_a(const __amdgpu_buffer_rsrc_t rsrc, const int lane_off, const int kb, const int ld4)
+// Packed image of one member (host: pack_member_wide; device: here).  Group of (layer l, k block kb, output block ob):
+//   hidden layers   g = base(l) + kb * nbU + ob,  base(0) = 0, base(l) = nbIn * nbU + (l - 1) * nbU * nbU
+//   mean head       g = baseH + kb * nbO + ob,    baseH = nbIn * nbU + (L - 1) * nbU * nbU
+//   variance head   g = baseH + nbU * nbO + kb * nbO + ob
+// and inside a group lane (q, j) holds W[16 kb + 4 q + r][16 ob + j] for r = 0..3 (zero past the matrix).
+__host__ __device__ inline int cem_wide_base(int l, int nbIn, int nbU) { return l == 0 ? 0 : nbIn * nbU + (l - 1) * nbU * nbU; }
+__host__ __device__ inline int cem_wide_groups(int L, int nbIn, int nbU, int nbO) { return nbIn * nbU + (L - 1) * nbU * nbU + 2 * nbU * nbO; }
+
+__device__ __forceinline__ f4 cem_wide_a(const __amdgpu_buffer_rsrc_t rsrc, const int lane16, const int g)
 {
-    f4 a;
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, g * 1024, 0));
+}
+
+// The k loop of one layer for a wave with NOWN output blocks (w, w + 4, ...): weights of k block kb + 1 are requested before the
+// MFMAs of k block kb.  NOWN is a template parameter so that a layer of, say, 10 blocks costs its waves 3 / 3 / 2 / 2 blocks, not 4 each.
+template <int NOWN>
+__device__ __forceinline__ void cem_wide_layer(f4 (&acc)[CEM_WIDE_OB], const __amdgpu_buffer_rsrc_t img, const int lane16, const int gl, const int nbK,
+                                               const int nbOut, const int w, const char *xin, const int lane)
+{
+    f4 a_nxt[NOWN];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) a[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_off, (16 * kb + r) * ld4, 0));
-    return a;
+    for (int i = 0; i < NOWN; ++i) a_nxt[i] = cem_wide_a(img, lane16, gl + w + 4 * i);
+    for (int kb = 0; kb < nbK; ++kb) {
+        f4 a_cur[NOWN];
+#pragma unroll
+        for (int i = 0; i < NOWN; ++i) a_cur[i] = a_nxt[i];
+        if (kb + 1 < nbK) {
+#pragma unroll
+            for (int i = 0; i < NOWN; ++i) a_nxt[i] = cem_wide_a(img, lane16, gl + (kb + 1) * nbOut + w + 4 * i);
+        }
+        const f4 hb = *reinterpret_cast<const f4 *>(xin + (kb * 64 + lane) * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < NOWN; ++i) acc[i] = CEM_MFMA(a_cur[i][r], hb[r], acc[i]);
+    }
 }
 
 __global__ __launch_bounds__(256) void cem_rollout_wide_kernel(const WideParams wp)
@@ -56,9 +87,10 @@ __global__ __launch_bounds__(256) void cem_rollout_wide_kernel(const WideParams 
     auto offb = [&](int l) { return offW(l) + (size_t)(l == 0 ? D : U) * U; };
     const size_t oWmu = (size_t)D * U + U + (size_t)(L - 1) * ((size_t)U * U + U), obmu = oWmu + (size_t)U * O;
     const size_t oWv = obmu + O, obv = oWv + (size_t)U * O;
-    auto rsrc_of = [&](const float *base, int words) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, words * 4, 0x00020000);
-    };
+    const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<f4 *>(wp.wimg + (size_t)__builtin_amdgcn_readfirstlane(td.member) * wp.img_f4), 0, wp.img_f4 * 16, 0x00020000);
+    const int lane16 = lane * 16;
+    const int baseH = cem_wide_base(L, nbIn, nbU);         // = nbIn * nbU + (L - 1) * nbU * nbU
 
     // ---- state registers: wave w owns input feature blocks Fo = w + 4 i (i < 2: obs+act <= 128) ---------------------
     const int slot0 = j < td.cnt ? j : td.cnt - 1;
@@ -111,35 +143,20 @@ __global__ __launch_bounds__(256) void cem_rollout_wide_kernel(const WideParams 
             CEM_WIDE_BOOKKEEP(t - 1);
             // ---- dense layers: h = relu(h W + b)  (mlp_ensemble.py:18-22): wave w computes output blocks w, w + 4, w + 8, w + 12 ----
             for (int l = 0; l < L; ++l) {
-                const int in = l == 0 ? D : U, nbK = l == 0 ? nbIn : nbU;
-                const __amdgpu_buffer_rsrc_t rs = rsrc_of(Wm + offW(l), in * U);
+                const int nbK = l == 0 ? nbIn : nbU;
+                const int gl = cem_wide_base(l, nbIn, nbU);
                 const float *bl = Wm + offb(l);
                 f4 acc[CEM_WIDE_OB];
-                int loff[CEM_WIDE_OB];
 #pragma unroll
-                for (int i = 0; i < CEM_WIDE_OB; ++i) {
-                    const int n = 16 * (w + 4 * i) + j;                              // this lane's output column as the A operand
-                    loff[i] = n < U ? (4 * q * U + n) * 4 : 0x7fffff00;
+                for (int i = 0; i < CEM_WIDE_OB; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { const int o = 16 * (w + 4 * i) + 4 * q + r; acc[i][r] = o < U ? bl[o] : 0.f; }
-                }
                 const char *xin = smem + (xw ^ XB);
-                f4 a_nxt[CEM_WIDE_OB];
-#pragma unroll
-                for (int i = 0; i < CEM_WIDE_OB; ++i) a_nxt[i] = cem_wide_a(rs, loff[i], 0, U * 4);
-                for (int kb = 0; kb < nbK; ++kb) {
-                    f4 a_cur[CEM_WIDE_OB];
-#pragma unroll
-                    for (int i = 0; i < CEM_WIDE_OB; ++i) a_cur[i] = a_nxt[i];
-                    if (kb + 1 < nbK) {                                               // the next k block's weights, a block ahead
-#pragma unroll
-                        for (int i = 0; i < CEM_WIDE_OB; ++i) a_nxt[i] = cem_wide_a(rs, loff[i], kb + 1, U * 4);
-                    }
-                    const f4 hb = *reinterpret_cast<const f4 *>(xin + (kb * 64 + lane) * 16);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int i = 0; i < CEM_WIDE_OB; ++i) acc[i] = CEM_MFMA(a_cur[i][r], hb[r], acc[i]);
+                switch ((nbU - w + 3) >> 2) {                                         // output blocks this wave owns (wave-uniform)
+                case 1: cem_wide_layer<1>(acc, img, lane16, gl, nbK, nbU, w, xin, lane); break;
+                case 2: cem_wide_layer<2>(acc, img, lane16, gl, nbK, nbU, w, xin, lane); break;
+                case 3: cem_wide_layer<3>(acc, img, lane16, gl, nbK, nbU, w, xin, lane); break;
+                default: cem_wide_layer<4>(acc, img, lane16, gl, nbK, nbU, w, xin, lane); break;
                 }
 #pragma unroll
                 for (int i = 0; i < CEM_WIDE_OB; ++i) {
@@ -197,13 +214,11 @@ __global__ __launch_bounds__(256) void cem_rollout_wide_kernel(const WideParams 
             }
             eps4 = eps4 * sampling;
             if (t >= 0 && Fo < nbO) {                      // wave-uniform: mean and variance heads of observation block Fo
-                const __amdgpu_buffer_rsrc_t rm = rsrc_of(Wm + oWmu, U * O), rv = rsrc_of(Wm + oWv, U * O);
-                const int n = 16 * Fo + j;
-                const int lo = n < O ? (4 * q * O + n) * 4 : 0x7fffff00;
-                f4 am = cem_wide_a(rm, lo, 0, O * 4), av = cem_wide_a(rv, lo, 0, O * 4);
+                const int gm = baseH + Fo, gv = baseH + nbU * nbO + Fo;
+                f4 am = cem_wide_a(img, lane16, gm), av = cem_wide_a(img, lane16, gv);
                 for (int kb = 0; kb < nbU; ++kb) {
                     const f4 cm = am, cv = av;
-                    if (kb + 1 < nbU) { am = cem_wide_a(rm, lo, kb + 1, O * 4); av = cem_wide_a(rv, lo, kb + 1, O * 4); }
+                    if (kb + 1 < nbU) { am = cem_wide_a(img, lane16, gm + (kb + 1) * nbO); av = cem_wide_a(img, lane16, gv + (kb + 1) * nbO); }
                     const f4 hb = *reinterpret_cast<const f4 *>(hL + (kb * 64 + lane) * 16);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { accm = CEM_MFMA(cm[r], hb[r], accm); accv = CEM_MFMA(cv[r], hb[r], accv); }
