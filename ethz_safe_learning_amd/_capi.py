@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-CEM_ABI_VERSION = 2
+CEM_ABI_VERSION = 3
 CEM_MAX_ACT = 32
 CEM_MAX_COST_KINDS = 4
 CEM_COMM_ID_BYTES = 128
@@ -45,7 +45,7 @@ class CemConfig(C.Structure):
         ('units', C.c_int32), ('n_layers', C.c_int32), ('ensemble_size', C.c_int32),
         ('particles', C.c_int32), ('n_samples', C.c_int32), ('horizon', C.c_int32),
         ('n_elite', C.c_int32), ('iterations', C.c_int32),
-        ('smoothing', C.c_float), ('stddev_threshold', C.c_float), ('noise_stddev', C.c_float),
+        ('smoothing', C.c_float), ('one_minus_smoothing', C.c_float), ('stddev_threshold', C.c_float), ('noise_stddev', C.c_float),
         ('variant', C.c_int32), ('posterior_mean_threashold', C.c_float),
         ('sampling_propagation', C.c_int32), ('scale_features', C.c_int32),
         ('act_lb', C.c_float * CEM_MAX_ACT), ('act_ub', C.c_float * CEM_MAX_ACT),

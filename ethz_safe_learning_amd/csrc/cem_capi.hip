@@ -40,6 +40,7 @@ int validate(const cem_config_t *c)
         c->n_elite < 1 || c->n_elite > c->n_samples || c->world_size < 1 || c->rank < 0 || c->rank >= c->world_size)
         return CEM_ERR_INVALID_ARG;
     if (c->units < 1) return CEM_ERR_INVALID_ARG;
+    if (!(fabs((double)c->one_minus_smoothing - (1.0 - (double)c->smoothing)) <= 2e-7)) return CEM_ERR_INVALID_ARG;   // see cem_mpc.h
     if (c->units > CEM_WIDE_U) return CEM_ERR_UNSUPPORTED;  // <= 128: the fast kernel (narrower layers run zero-padded, exactly); 129..256: cem_rollout_wide.h
     if (c->obs_dim + c->act_dim > CEM_U) return CEM_ERR_UNSUPPORTED;
     if (c->n_samples % c->world_size != 0) return CEM_ERR_INVALID_ARG;
@@ -828,7 +829,7 @@ int enqueue_select(cem_planner *h, int it)
     SelectParams p{}; p.scores = (const float *)(ws + l.scores_global); p.actions = (const float *)(ws + l.actions);
     p.musig = (float *)(ws + l.musig); p.ctrl = (CtrlBlock *)(ws + l.ctrl); p.elite_idx = (int32_t *)(ws + l.elite);
     p.N = d.N; p.k = d.k; p.HA = d.H * d.A; p.A = d.A; p.check_done = 1;
-    p.smoothing = h->cfg.smoothing; p.threshold = h->cfg.stddev_threshold;
+    p.smoothing = h->cfg.smoothing; p.one_minus_smoothing = h->cfg.one_minus_smoothing; p.threshold = h->cfg.stddev_threshold;
     p.stamps = (long long *)(ws + l.stamps) + 64;          // past tile 0's rollout stamps; written by -DCEM_STAMPS builds only
     size_t lds = (size_t)((d.k + 3) & ~3) * 4 + (size_t)2 * d.H * d.A * 4;
     const size_t dyn_limit = h->sel_dyn_limit;          // asked from the runtime at create(), per device
@@ -842,7 +843,7 @@ int enqueue_select(cem_planner *h, int it)
         m.hist = (uint32_t *)(ws + l.ms_hist); m.sel = (uint32_t *)(ws + l.ms_sel); m.wg_counts = (uint32_t *)(ws + l.ms_counts);
         m.best_sc = (float *)(ws + l.ms_best_sc); m.best_ix = (int32_t *)(ws + l.ms_best_ix);
         m.part = (float *)(ws + l.ms_part); m.colmean = (float *)(ws + l.ms_colmean);
-        m.N = d.N; m.k = d.k; m.HA = p.HA; m.A = d.A; m.check_done = 1; m.smoothing = p.smoothing; m.threshold = p.threshold;
+        m.N = d.N; m.k = d.k; m.HA = p.HA; m.A = d.A; m.check_done = 1; m.smoothing = p.smoothing; m.one_minus_smoothing = p.one_minus_smoothing; m.threshold = p.threshold;
         m.G = (d.N + CEM_MS_KEYS - 1) / CEM_MS_KEYS; m.G2 = (d.k + CEM_MS_EPG - 1) / CEM_MS_EPG;
         HIPCHK(hipMemsetAsync(m.hist, 0, 3 * CEM_MS_BINS * 4, h->stream));
         hipLaunchKernelGGL(cem_msel_hist_kernel<0>, dim3(m.G), dim3(1024), 0, h->stream, m);

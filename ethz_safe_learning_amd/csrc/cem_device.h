@@ -289,8 +289,9 @@ __device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], f
 // acquire / release FENCE would make them so by invalidating / writing back the whole L2 (buffer_inv sc1 / buffer_wbl2 sc1),
 // i.e. by evicting the ensemble weights every other workgroup of the XCD is streaming from it — measured 2.8x slower.  So the
 // few KB of state move with sc1 loads and stores (performed at the device coherence point, no cache maintenance — what an
-// agent-scope relaxed atomic access is on gfx940+), the flag likewise, and the order "state, then flag" is kept by waiting for
-// the stores' acknowledgements (s_waitcnt vmcnt(0)) before the flag is written.
+// agent-scope relaxed atomic access is on gfx940+), the flag likewise, and the order "state, then flag" is kept by EVERY wave
+// waiting for its own stores' acknowledgements (an explicit s_waitcnt vmcnt(0)) before the workgroup barrier that precedes the
+// flag store (a barrier alone does not drain stores on gfx940+, nor does a workgroup-scope fence).
 // ... as 16-byte buffer accesses with the sc1 cache-policy bit (aux bit 4 on gfx940+), the same instruction form the compiler
 // emits for agent-scope relaxed atomics, four words at a time.
 typedef unsigned int cem_u4 __attribute__((ext_vector_type(4)));
@@ -691,7 +692,10 @@ __global__ __launch_bounds__(256) void cem_rollout_seg_kernel(const RolloutParam
     const int t0 = seg * p.seg_len, t1 = (t0 + p.seg_len < p.H) ? t0 + p.seg_len : p.H;
     cem_rollout_tile<RC, NFW, 0, true>(p, smem, tile, t0, t1);
     if (t1 < p.H) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // s_waitcnt vmcnt(0): this wave's state stores are acknowledged
+        // EVERY wave waits for the acknowledgements of its own sc1 state stores (vmcnt(0); the encoding leaves expcnt / lgkmcnt
+        // alone) before the barrier: s_barrier does not drain stores on gfx940+, and a workgroup-scope release fence compiles
+        // to no wait at all here.  tests/test_capi_cpu.py checks the ISA for this wait between the last sc1 store and the barrier.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
         if (threadIdx.x == 0) {
             const uint32_t pos = atomicAdd(p.seg_queue + 1, 1u);
@@ -916,7 +920,7 @@ __global__ __launch_bounds__(256) void cem_scorer_kernel(const ScorerOpParams p)
 struct SelectParams {
     const float *scores; const float *actions; float *musig; CtrlBlock *ctrl; int32_t *elite_idx;
     int32_t N, k, HA, A, check_done;
-    float smoothing, threshold;
+    float smoothing, one_minus_smoothing, threshold;   // one_minus_smoothing = fl32(1.0 - smoothing) rounded once, as cem_mpc.py:64-65 does
     long long *stamps;           // [8] section stamps of -DCEM_STAMPS diagnostic builds
 };
 
@@ -1118,7 +1122,7 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
     CEM_SEL_STAMP(4);
     // ---- moments over the elite set (tf.nn.moments: mean, then mean squared difference) ---------------------
     const float fk = (float)k;
-    const float sm = p.smoothing;
+    const float sm = p.smoothing, osm = p.one_minus_smoothing;
     // Wide path for large elite sets (the replicated select of a multi-GPU plan): a thread gathers whole float4s of an elite's
     // action row, i.e. a quarter of the address arithmetic and load instructions per element — this kernel is issue-bound
     // on its one CU.  Partial sums still add up in a fixed order (elite index ascending within a part, parts ascending).
@@ -1168,8 +1172,8 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
                         for (int r = 0; r < 4; ++r) {
                             const float sd = sqrtf(tot[r] / fk);
                             const int ci = 4 * c4 + r;
-                            const float nsg = sm * p.musig[HA + ci] + (1.0f - sm) * sd;                // cem_mpc.py:65
-                            p.musig[ci] = sm * p.musig[ci] + (1.0f - sm) * colmean[ci];                // cem_mpc.py:64
+                            const float nsg = sm * p.musig[HA + ci] + osm * sd;                // cem_mpc.py:65
+                            p.musig[ci] = sm * p.musig[ci] + osm * colmean[ci];                // cem_mpc.py:64
                             p.musig[HA + ci] = nsg;
                             newsig[ci] = nsg;
                         }
@@ -1223,8 +1227,8 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
                     const float sd = sqrtf(tot / fk);
                     const int ci = cb + col;
                     const float omu = cb == 0 ? old_mu : p.musig[ci], osg = cb == 0 ? old_sg : p.musig[HA + ci];
-                    const float nsg = sm * osg + (1.0f - sm) * sd;                             // cem_mpc.py:65
-                    p.musig[ci] = sm * omu + (1.0f - sm) * colmean[ci];                        // cem_mpc.py:64
+                    const float nsg = sm * osg + osm * sd;                             // cem_mpc.py:65
+                    p.musig[ci] = sm * omu + osm * colmean[ci];                        // cem_mpc.py:64
                     p.musig[HA + ci] = nsg;
                     newsig[ci] = nsg;
                 }
@@ -1278,7 +1282,7 @@ struct MSelParams {
     float *part;                      // [2][G2][HA] partial sums of the two moment passes
     float *colmean;                   // [HA] elite mean, later the smoothed sigma
     int32_t N, k, HA, A, check_done, G, G2;
-    float smoothing, threshold;
+    float smoothing, one_minus_smoothing, threshold;   // one_minus_smoothing = fl32(1.0 - smoothing) rounded once, as cem_mpc.py:64-65 does
 };
 
 // block-wide (1024 threads): the bin b with ge[b] >= need > ge[b + 1], ge[b] = #keys in bins >= b; returns (b, need - ge[b + 1])
@@ -1466,13 +1470,13 @@ __global__ __launch_bounds__(256) void cem_msel_final_kernel(const MSelParams p)
 {
     if (p.check_done && p.ctrl->done) return;
     const int tid = threadIdx.x;
-    const float fk = (float)p.k, sm = p.smoothing;
+    const float fk = (float)p.k, sm = p.smoothing, osm = p.one_minus_smoothing;
     for (int col = tid; col < p.HA; col += 256) {
         float t = 0.f;
         for (int g = 0; g < p.G2; ++g) t = t + p.part[((size_t)p.G2 + g) * p.HA + col];
         const float sd = sqrtf(t / fk);
-        const float nsg = sm * p.musig[p.HA + col] + (1.0f - sm) * sd;                   // cem_mpc.py:65
-        p.musig[col] = sm * p.musig[col] + (1.0f - sm) * p.colmean[col];                 // cem_mpc.py:64
+        const float nsg = sm * p.musig[p.HA + col] + osm * sd;                   // cem_mpc.py:65
+        p.musig[col] = sm * p.musig[col] + osm * p.colmean[col];                 // cem_mpc.py:64
         p.musig[p.HA + col] = nsg;
     }
     __syncthreads();

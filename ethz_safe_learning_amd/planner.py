@@ -81,6 +81,8 @@ def to_c_config(cfg: PlannerConfig) -> _capi.CemConfig:
     c.ensemble_size, c.particles, c.n_samples = cfg.ensemble_size, cfg.particles, cfg.n_samples
     c.horizon, c.n_elite, c.iterations = cfg.horizon, cfg.n_elite, cfg.iterations
     c.smoothing, c.stddev_threshold, c.noise_stddev = cfg.smoothing, cfg.stddev_threshold, cfg.noise_stddev
+    # `(1.0 - self.smoothing)` is a Python-float difference that TF converts once to fp32 (cem_mpc.py:64-65)
+    c.one_minus_smoothing = float(np.float32(1.0 - float(cfg.smoothing)))
     if cfg.variant not in ('cem', 'safe'):
         raise ValueError("variant must be 'cem' or 'safe'")
     c.variant = 1 if cfg.variant == 'safe' else 0

@@ -23,6 +23,7 @@ def main(seed=0):
     cfg.obs_dim, cfg.act_dim, cfg.units, cfg.n_layers, cfg.ensemble_size = O, A, U, L, E
     cfg.particles, cfg.n_samples, cfg.horizon, cfg.n_elite, cfg.iterations = E, 400, 12, 40, 4
     cfg.smoothing, cfg.stddev_threshold, cfg.noise_stddev = 0.1, 0.0, 0.01
+    cfg.one_minus_smoothing = float(np.float32(1.0 - 0.1))                     # fl32 of the Python-float difference (cem_mpc.py:64-65)
     cfg.variant, cfg.posterior_mean_threashold = 0, 0.15                       # 0 = CemMpc objective, 1 = SafeCemMpc
     cfg.sampling_propagation, cfg.scale_features = 1, 1
     for a in range(A):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CEM_ABI_VERSION 2
+#define CEM_ABI_VERSION 3
 #define CEM_MAX_ACT 32
 #define CEM_MAX_COST_KINDS 4
 
@@ -86,6 +86,10 @@ typedef struct cem_config {
     int32_t n_elite;              /* k */
     int32_t iterations;           /* I */
     float smoothing;
+    float one_minus_smoothing;    /* the factor `(1.0 - self.smoothing)` of cem_mpc.py:64-65 as the reference rounds it: a Python-float
+                                   * difference converted ONCE to an fp32 tensor, fl32(1.0 - smoothing) evaluated in double — NOT
+                                   * 1.0f - fl32(smoothing), which is one ulp off for 41 of the 99 two-decimal smoothing values
+                                   * (0.09, 0.16, 0.29, 0.33 ...).  Must lie within 2e-7 of 1 - smoothing (else CEM_ERR_INVALID_ARG) */
     float stddev_threshold;
     float noise_stddev;
     int32_t variant;              /* enum cem_variant */

@@ -143,8 +143,11 @@ def plan(state, sw, inputs_min, inputs_max, low, high, eps_act, eps_model, eps_o
         el = a[elite]
         mean = el.sum(dim=0) / float(k)                                      # tf.nn.moments: population variance
         var_e = ((el - mean) ** 2).sum(dim=0) / float(k)
-        mu = cfg.smoothing * mu + (1.0 - cfg.smoothing) * mean
-        sigma = cfg.smoothing * sigma + (1.0 - cfg.smoothing) * torch.sqrt(var_e)
+        # cem_mpc.py:64-65: both factors are Python floats rounded once to fp32 (torch converts a Python scalar the same way)
+        s32 = float(torch.tensor(float(cfg.smoothing), dtype=torch.float32))
+        oms32 = float(torch.tensor(1.0 - float(cfg.smoothing), dtype=torch.float32))
+        mu = s32 * mu + oms32 * mean
+        sigma = s32 * sigma + oms32 * torch.sqrt(var_e)
         iters += 1
         if trace is not None:
             trace.append(dict(actions=a.numpy().copy(), scores=scores.numpy().copy(), elite=elite.numpy().copy(),

@@ -36,7 +36,7 @@ def make(variant, path):
         for b in w['b']:
             b[:] = rng.normal(0, 0.05, b.shape)
         w['b_mu'][:] = rng.normal(0, 0.01, O)
-    cfg = o.PlanConfig(horizon=H, iterations=I, n_samples=N, n_elite=k, particles=P, ensemble_size=E, smoothing=0.1,
+    cfg = o.PlanConfig(horizon=H, iterations=I, n_samples=N, n_elite=k, particles=P, ensemble_size=E, smoothing=0.09,
                        stddev_threshold=-1.0, noise_stddev=0.05, variant=variant, posterior_mean_threashold=0.45)
     ea = rng.standard_normal((I, N, H, A)).astype(np.float32)
     em = rng.standard_normal((I, H, P * N, O)).astype(np.float32)
@@ -55,7 +55,7 @@ def make(variant, path):
         res[name + '_sigma'] = np.stack([t['sigma'] for t in tr])
         res[name + '_actions'] = np.stack([t['actions'] for t in tr])
     sp = pb['scorer']
-    np.savez_compressed(path, variant=variant, dims=np.array([O, A, E, U, L, N, H, P, k, I]), smoothing=0.1, noise_stddev=0.05,
+    np.savez_compressed(path, variant=variant, dims=np.array([O, A, E, U, L, N, H, P, k, I]), smoothing=0.09, noise_stddev=0.05,
                         posterior=0.45, state=pb['state'], inputs_min=pb['inputs_min'], inputs_max=pb['inputs_max'],
                         low=pb['low'], high=pb['high'], goal_slice=np.array(sp.goal_slice),
                         cost_kinds=np.array(sp.cost_kinds, np.float64), eps_act=ea, eps_model=em, eps_out=eo,

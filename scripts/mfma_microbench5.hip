@@ -1,0 +1,109 @@
+// Microbenchmark (round 3): what ONE instruction of each class costs beside v_mfma_f32_16x16x4_f32 on gfx950.
+//   hipcc --offload-arch=gfx950 -O3 -o mfma_mb5 mfma_microbench5.hip && ./mfma_mb5
+// Part A: one wave per SIMD, K fillers of one class issued after every MFMA (2 independent accumulators): cycles per MFMA gap.
+// Part B: two waves per SIMD, one issuing only MFMAs and one issuing only fillers: does the filler wave's work overlap with the
+//         other wave's fp32 MFMAs (time = max) or serialise with it (time = sum)?
+// The rollout epilogue's instruction classes: plain fp32 VALU, packed fp32 (what -O3 SLP-packs adjacent scalar ops into),
+// 64-bit integer multiply-add (Philox), transcendentals (Box-Muller, softplus), integer logic, v_mov, cross-lane swaps, LDS reads.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+enum Op { NONE, FMA, MUL, XOR, MOV, PKMUL, PKFMA, MAD64, EXP, SQRT, SIN, MAX, CNDMASK, PERMSWAP, DSREAD, SNOP, CVT, MULLO };
+static const char *op_name[] = {"none", "v_fma_f32", "v_mul_f32", "v_xor_b32", "v_mov_b32", "v_pk_mul_f32", "v_pk_fma_f32", "v_mad_u64_u32",
+                                "v_exp_f32", "v_sqrt_f32", "v_sin_f32", "v_max_f32", "v_cndmask_b32", "v_permlane16_swap", "ds_read_b128", "s_nop 0",
+                                "v_cvt_f32_u32", "v_mul_lo_u32"};
+
+template <int OP>
+__device__ __forceinline__ void filler(float &x, float &y, f2 &p, f2 &q, unsigned long long &u, unsigned &m, f4 &l, const char *lds, float c)
+{
+    if (OP == FMA) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x) : "v"(c));
+    if (OP == MUL) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x) : "v"(c));
+    if (OP == XOR) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(m) : "v"(c));
+    if (OP == MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "v"(x));
+    if (OP == PKMUL) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p) : "v"(q));
+    if (OP == PKFMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p) : "v"(q));
+    if (OP == MAD64) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(u) : "v"(m), "v"(c) : "vcc");
+    if (OP == EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(x));
+    if (OP == SQRT) asm volatile("v_sqrt_f32 %0, %0" : "+v"(x));
+    if (OP == SIN) asm volatile("v_sin_f32 %0, %0" : "+v"(x));
+    if (OP == MAX) asm volatile("v_max_f32 %0, %0, %1" : "+v"(x) : "v"(c));
+    if (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(c) : );
+    if (OP == PERMSWAP) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    if (OP == DSREAD) asm volatile("ds_read_b128 %0, %1" : "=v"(l) : "v"((unsigned)(size_t)lds));
+    if (OP == SNOP) asm volatile("s_nop 0");
+    if (OP == CVT) asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(y) : "v"(m));
+    if (OP == MULLO) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(m) : "v"(c));
+}
+
+// ROLE 0: MFMAs with K fillers each.  ROLE 1 (part B): even waves (w < 4) MFMA only, odd waves (w >= 4) fillers only
+template <int OP, int K, int ROLE>
+__global__ __launch_bounds__(512) void kern(float *out, long long *cyc, int iters, float seed)
+{
+    __shared__ __attribute__((aligned(16))) char lds[4096];
+    const int w = threadIdx.x >> 6;
+    f4 acc0 = (f4){seed, seed, seed, seed}, acc1 = acc0;
+    float a = seed + threadIdx.x, b = seed * 2 + threadIdx.x;
+    float x[4] = {seed, seed + 1, seed + 2, seed + 3}, y = 0.f;
+    f2 p[4] = {{seed, 1.f}, {seed, 2.f}, {seed, 3.f}, {seed, 4.f}}, q = {1.0001f, 0.999f};
+    unsigned long long u = 0; unsigned m[4] = {threadIdx.x, 2, 3, 4}; f4 l = {0, 0, 0, 0};
+    const bool do_mfma = ROLE == 0 || w < 4, do_fill = ROLE == 0 || w >= 4;
+    __syncthreads();
+    long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int uu = 0; uu < 32; ++uu) {
+            if (do_mfma) {
+                if (uu & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc0, 0, 0, 0);
+            }
+            if (do_fill) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) filler<OP>(x[k & 3], y, p[k & 3], q, u, m[k & 3], l, lds + (threadIdx.x & 63) * 16, 1.0001f);
+            }
+        }
+        if (OP == DSREAD) asm volatile("s_waitcnt lgkmcnt(0)");
+    }
+    long long t1 = __builtin_amdgcn_s_memtime();
+    float s = acc0[0] + acc1[1] + x[0] + x[1] + x[2] + x[3] + y + p[0][0] + p[1][1] + p[2][0] + p[3][1] + (float)u + (float)(m[0] ^ m[1] ^ m[2] ^ m[3]) + l[0];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + w] = t1 - t0;
+}
+
+static float *g_out; static long long *g_cyc;
+
+template <int OP, int K, int ROLE> double run(int threads, int blocks = 256)
+{
+    const int iters = 400;
+    hipLaunchKernelGGL((kern<OP, K, ROLE>), dim3(blocks), dim3(threads), 0, 0, g_out, g_cyc, 4, 1.0f);
+    hipDeviceSynchronize();
+    hipLaunchKernelGGL((kern<OP, K, ROLE>), dim3(blocks), dim3(threads), 0, 0, g_out, g_cyc, iters, 1.0f);
+    hipDeviceSynchronize();
+    long long c[8]; hipMemcpy(c, g_cyc, 64, hipMemcpyDeviceToHost);
+    long long mx = 0; for (int i = 0; i < threads / 64; ++i) mx = c[i] > mx ? c[i] : mx;
+    return (double)mx / (iters * 32.0);
+}
+
+template <int OP> void partA()
+{
+    const double k0 = run<NONE, 0, 0>(256), k1 = run<OP, 1, 0>(256), k2 = run<OP, 2, 0>(256), k4 = run<OP, 4, 0>(256), k8 = run<OP, 8, 0>(256);
+    printf("A %-18s cycles per MFMA gap with 0/1/2/4/8 fillers: %6.1f %6.1f %6.1f %6.1f %6.1f   => per filler (8): %5.2f\n", op_name[OP], k0, k1, k2, k4, k8, (k8 - k0) / 8);
+}
+template <int OP> void partB()
+{
+    // 4 fillers per (absent) MFMA slot on the filler wave; the MFMA wave alone; both
+    const double both = run<OP, 4, 1>(512);
+    const double fill_alone = run<OP, 4, 0>(256) - 0.0;   // (with its own MFMAs: reference only)
+    printf("B %-18s MFMA wave + filler wave (4 per slot) on one SIMD: %6.1f cycles per slot  (one wave doing both: %6.1f)\n", op_name[OP], both, fill_alone);
+}
+
+int main()
+{
+    hipMalloc(&g_out, 256 * 512 * 4); hipMalloc(&g_cyc, 256 * 64);
+    partA<FMA>(); partA<MUL>(); partA<MAX>(); partA<XOR>(); partA<MOV>(); partA<CNDMASK>(); partA<CVT>();
+    partA<PKMUL>(); partA<PKFMA>(); partA<MAD64>(); partA<MULLO>(); partA<EXP>(); partA<SQRT>(); partA<SIN>();
+    partA<PERMSWAP>(); partA<DSREAD>(); partA<SNOP>();
+    partB<FMA>(); partB<XOR>(); partB<PKMUL>(); partB<MAD64>(); partB<EXP>(); partB<DSREAD>();
+    return 0;
+}

@@ -310,6 +310,38 @@ def test_select_edge_cases(case, mode):
     np.testing.assert_allclose(ms[1], np.sqrt(var), rtol=2e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize('mode', [0, 1, 2])
+def test_smoothing_blend_rounds_each_factor_once(mode):
+    """cem_mpc.py:64-65 at smoothing = 0.09, where fl32(1.0 - s) and 1.0f - fl32(s) differ by one ulp: with a single elite the
+    moments are exact (mean = that candidate's actions, variance 0), so the refit is two products and a sum — compared bit for bit
+    with the reference's rounding (each Python-float factor converted once to fp32)."""
+    torch = _torch()
+    pb = hp.make_problem(seed=44)
+    N, H, s = 256, 5, 0.09
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=5, E=5, k=1, I=1, smoothing=s, select_mode=mode)
+    pl = hp.make_planner(pb, pcfg)
+    ea, em, eo = hp.noise(1, N, H, 2, 5, 60, seed=4)
+    actions, _, _ = _run_iteration(pl, pb, ocfg, ea, em)
+    ms0 = pl.mu_sigma().cpu().numpy().copy()
+    sc = np.random.default_rng(3).standard_normal(N).astype(np.float32)
+    pl.scores_global().copy_(torch.from_numpy(sc))
+    torch.cuda.synchronize()
+    pl.plan_select(0)
+    torch.cuda.synchronize()
+    j = int(np.argmax(sc))
+    assert list(pl.elite_idx().cpu().numpy()) == [j]
+    once, twice = np.float32(1.0 - s), np.float32(1.0) - np.float32(s)
+    assert once != twice
+    ms1 = pl.mu_sigma().cpu().numpy()
+    want_mu = np.float32(s) * ms0[0] + once * actions[j].reshape(ms0[0].shape)
+    np.testing.assert_array_equal(ms1[0], want_mu)
+    np.testing.assert_array_equal(ms1[1], np.float32(s) * ms0[1] + once * np.zeros_like(ms0[1]))
+    assert np.any(want_mu != np.float32(s) * ms0[0] + twice * actions[j].reshape(ms0[0].shape))
+    mu, sigma, *_ = o.select_and_refit(sc, actions, ms0[0].reshape(H, 2), ms0[1].reshape(H, 2), np.zeros(2, np.float32), np.float32(-np.inf), ocfg)
+    np.testing.assert_array_equal(ms1[0].reshape(H, 2), mu)
+    pl.plan_end(eps_out=np.zeros(2, np.float32))
+
+
 def test_select_wide_moments_path_matches_oracle():
     """The select kernel of a weak-scaled 8-GPU plan: N = 16000 candidates, k = 1600 elites, H*A = 60 — large k takes the
     float4 gather path of the moments.  Elite set exact on the GPU's own scores; mu / sigma / best action vs the oracle."""

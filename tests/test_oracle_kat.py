@@ -214,6 +214,29 @@ def test_plan_returns_best_sampled_first_action_plus_noise():
     np.testing.assert_allclose(tr[0]['sigma'], np.sqrt(v), rtol=1e-6)
 
 
+def test_smoothing_factors_are_each_rounded_once():
+    """cem_mpc.py:64-65: `self.smoothing * mu + (1.0 - self.smoothing) * mean` — both factors are Python floats that TF converts
+    once to fp32, so the second one is fl32(1.0 - s) evaluated in double.  At s = 0.09 that differs by one ulp from
+    1.0f - fl32(s), the form rounds 1 and 2 of this repo used on both sides."""
+    s = 0.09
+    once = np.float32(1.0 - s)
+    twice = np.float32(1.0) - np.float32(s)
+    assert once != twice and abs(float(once) - float(twice)) < 1e-7          # the case is a discriminating one
+    n_diff = sum(np.float32(1.0 - i / 100.0) != np.float32(1.0) - np.float32(i / 100.0) for i in range(1, 100))
+    assert n_diff == 41
+    rng = np.random.default_rng(5)
+    N, H, A, k = 8, 3, 2, 1
+    actions = rng.uniform(-1, 1, (N, H, A)).astype(np.float32)
+    scores = np.arange(N, dtype=np.float32)                                  # elite = the last candidate alone: var = 0 exactly
+    mu0 = rng.uniform(-1, 1, (H, A)).astype(np.float32)
+    sg0 = rng.uniform(0.5, 1, (H, A)).astype(np.float32)
+    cfg = o.PlanConfig(horizon=H, iterations=1, n_samples=N, n_elite=k, particles=1, ensemble_size=1, smoothing=s)
+    mu, sigma, *_ = o.select_and_refit(scores, actions, mu0, sg0, np.zeros(A, np.float32), np.float32(-np.inf), cfg)
+    np.testing.assert_array_equal(mu, np.float32(s) * mu0 + once * actions[N - 1])
+    np.testing.assert_array_equal(sigma, np.float32(s) * sg0 + once * np.zeros((H, A), np.float32))
+    assert np.any(mu != np.float32(s) * mu0 + twice * actions[N - 1])
+
+
 def test_early_stop_runs_at_least_one_iteration():
     pb, cfg, ea, em, eo = _tiny(thr=10.0)              # mean(sigma) <= 10 after the first refit (cem_mpc.py:66-67)
     a, s, it = o.do_generate_action(pb['state'], pb['weights'], pb['inputs_min'], pb['inputs_max'], pb['low'], pb['high'],
