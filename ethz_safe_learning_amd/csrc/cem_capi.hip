@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -26,6 +27,7 @@ struct Dims {
     int O, A, Din, U, L, E, P, N, H, k, I, W, R;
     int Nloc, n_off, Bloc, Btot;
     int KB_in, KB_obs, NFW, KF0;     // KF0 = 4*NFW: layer-0 groups per wave, zero padded so every stage is a multiple of 4
+    int act_q0, act_nq;              // feature quads of the network input that hold action features: [act_q0, act_q0 + act_nq)
     bool wide;                       // units > 128: the width-generic rollout kernel on the natural weight blob (cem_rollout_wide.h)
     int wave_groups[4]; uint32_t wave_off_f4[4]; uint32_t member_stride_f4;
     size_t nat_member_floats;
@@ -61,6 +63,10 @@ int validate(const cem_config_t *c)
     // flat int indices of the sample / rollout / reduce kernels: N*H*A and H*P*N/world must fit an int32
     if ((long long)c->n_samples * c->horizon * ((c->act_dim + 3) & ~3) > 0x7fffffffll) return CEM_ERR_UNSUPPORTED;
     if ((long long)c->particles * (c->n_samples / c->world_size) * c->horizon > 0x7fffffffll) return CEM_ERR_UNSUPPORTED;
+    {   // the hot kernel addresses the padded action quads with 32-bit byte offsets (one buffer resource)
+        const long long nq = (c->obs_dim + c->act_dim + 3) / 4 - c->obs_dim / 4;
+        if ((long long)c->n_samples * c->horizon * nq * 16 > 0x7fffffffll) return CEM_ERR_UNSUPPORTED;
+    }
     if (c->variant != CEM_VARIANT_CEM && c->variant != CEM_VARIANT_SAFE) return CEM_ERR_INVALID_ARG;
     if (c->chunks_per_tile < 0 || c->chunks_per_tile > 4) return CEM_ERR_INVALID_ARG;
     if (c->rollout_segments < 0 || c->rollout_segments > 64) return CEM_ERR_INVALID_ARG;
@@ -77,6 +83,7 @@ Dims make_dims(const cem_config_t *c)
     d.W = c->world_size; d.R = c->rank;
     d.Nloc = d.N / d.W; d.n_off = d.R * d.Nloc; d.Bloc = d.P * d.Nloc; d.Btot = d.P * d.N;
     d.KB_in = (d.Din + 15) / 16; d.KB_obs = (d.O + 15) / 16; d.NFW = (d.KB_in + 3) / 4; d.KF0 = 4 * d.NFW;
+    d.act_q0 = d.O / 4; d.act_nq = (d.Din + 3) / 4 - d.act_q0;
     d.wide = d.U > CEM_U;
     uint32_t off = 0;
     for (int w = 0; w < 4; ++w) {
@@ -222,41 +229,57 @@ void build_plan_tiles(const Dims &d, int rc, std::vector<Tile6> &out)
 static const double kChunkSolo[2][4] = {{0.192, 0.168, 0.159, 0.157}, {1.25, 1.056, 1.010, 0.999}};
 static const double kChunkShared[2][4] = {{0.153, 0.148, 0.1445, 0.1445}, {1.00, 0.949, 0.93, 0.92}};
 #define CEM_MAX_DEVICES 64
-static const int kResidentStatic[2][4] = {{3, 2, 2, 2}, {2, 2, 1, 1}};     // from the kernels' VGPR counts (155/181/221/249, 206/240/274/335)
+// workgroups of a <rc, nfw> tile one CU keeps resident, from the kernels' VGPR counts (plain / segment kernel, round 3: 139/159/186/218,
+// 165/217/253/288 and 144/163/190/223, 171/221/255/292; 512 registers per SIMD lane): the smaller of the two forms' answers
+static const int kResidentStatic[2][4] = {{3, 3, 2, 2}, {2, 2, 2, 1}};
 
 template <int RC, int NFW>
 int query_resident()
 {
-    int n = 0;
+    int n = 0, ns = 0;
     const size_t lds = (size_t)2 * RC * CEM_NG * 1024 + CEM_PART_FLOATS * 4;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cem_rollout_kernel<RC, NFW, 0>, 256, lds) != hipSuccess || n < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cem_rollout_kernel<RC, NFW, 0>, 256, lds) != hipSuccess || n < 1 ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&ns, cem_rollout_seg_kernel<RC, NFW>, 256, lds) != hipSuccess || ns < 1) {
         (void)hipGetLastError();
         return 0;
     }
-    return n;
+    return std::min(n, ns);
 }
 
-// workgroups of the <rc, nfw> hot kernel one CU keeps resident: asked from the runtime, static table without a device
-int resident_workgroups(int nfw, int rc)
+// Per-device facts the tile plan is priced with, asked from the runtime once per device (thread-safe: one std::call_once per
+// device slot; the last slot serves a process without a device and holds the static tables).
+struct DeviceFacts { std::once_flag once; int resident[2][4]; int cus; };
+static DeviceFacts g_facts[CEM_MAX_DEVICES + 1];
+
+const DeviceFacts &device_facts()
 {
-    // per device: occupancy is a property of the kernel's code object on the CURRENT device
-    static int cache[CEM_MAX_DEVICES + 1][2][4];
-    static bool init = false;
-    if (!init) { for (auto &d : cache) for (auto &f : d) for (int &v : f) v = -1; init = true; }
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = CEM_MAX_DEVICES; }     // no device: the static table's slot
     if (dev < 0 || dev > CEM_MAX_DEVICES) dev = CEM_MAX_DEVICES;
-    int &c = cache[dev][nfw - 1][rc - 1];
-    if (c < 0) {
-        int n = 0;
+    DeviceFacts &f = g_facts[dev];
+    std::call_once(f.once, [&] {
+        const bool have = dev < CEM_MAX_DEVICES;
+        for (int nfw = 1; nfw <= 2; ++nfw)
+            for (int rc = 1; rc <= 4; ++rc) {
+                int n = 0;
+                if (have) {
 #define CEM_CASE(R, F) if (rc == R && nfw == F) n = query_resident<R, F>();
-        CEM_CASE(1, 1) CEM_CASE(2, 1) CEM_CASE(3, 1) CEM_CASE(4, 1)
-        CEM_CASE(1, 2) CEM_CASE(2, 2) CEM_CASE(3, 2) CEM_CASE(4, 2)
+                    CEM_CASE(1, 1) CEM_CASE(2, 1) CEM_CASE(3, 1) CEM_CASE(4, 1)
+                    CEM_CASE(1, 2) CEM_CASE(2, 2) CEM_CASE(3, 2) CEM_CASE(4, 2)
 #undef CEM_CASE
-        c = n > 0 ? n : kResidentStatic[nfw - 1][rc - 1];
-    }
-    return c;
+                }
+                f.resident[nfw - 1][rc - 1] = n > 0 ? n : kResidentStatic[nfw - 1][rc - 1];
+            }
+        f.cus = 256;                                // MI355X; a partitioned or different device reports its own count
+        hipDeviceProp_t pr;
+        if (have && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) f.cus = pr.multiProcessorCount;
+        else (void)hipGetLastError();
+    });
+    return f;
 }
+
+int resident_workgroups(int nfw, int rc) { return device_facts().resident[nfw - 1][rc - 1]; }
+int num_cus() { return device_facts().cus; }
 
 // ---- pinned tiles + floating horizon segments ----------------------------------------------------------------------------
 // One workgroup per tile for the whole horizon makes the busiest CU carry ceil(tiles / CUs) tiles while the mean is
@@ -267,7 +290,6 @@ int resident_workgroups(int nfw, int rc)
 // no gain with ONE pinned tile per CU (375 / 470 tiles: 0.335 -> 0.335, 0.353 -> 0.373 ms: the pinned tile runs without a
 // partner and a floater's 30-step chain plus its hand-overs is as long as two whole tiles) and none when the remainder nearly
 // fills the CUs anyway (750 tiles: 0.498 -> 0.492).  Hence: at least two pinned tiles per CU, and a predicted gain of > 4 %.
-static const int kNumCUs = 256;             // MI355X; the balance arithmetic below is only used to DECIDE, any device runs either form
 static const int kSegMaxSegments = 6, kSegMinSteps = 5;
 static const double kFloatOverhead = 1.08;  // floating launch vs the mean-load ideal (B2: 0.405 ms vs 2.44 x 0.153 ms)
 
@@ -276,7 +298,7 @@ int segments_for(const Dims &d, int rc, size_t n_tiles, int requested)
     if (requested == 1 || n_tiles >= (size_t)1 << 23) return 1;       // items are packed as (tile << 8 | segment)
     auto clamp_to_horizon = [&](int S) { S = std::min(S, d.H); while (S > 1 && (d.H + S - 1) / S * (S - 1) >= d.H) --S; return std::max(S, 1); };
     if (requested > 1) return clamp_to_horizon(requested);
-    const int occ = resident_workgroups(d.NFW, rc);
+    const int occ = resident_workgroups(d.NFW, rc), kNumCUs = num_cus();
     if (n_tiles < (size_t)2 * kNumCUs || n_tiles > (size_t)kNumCUs * occ) return 1;  // < 2 pinned tiles per CU: no gain (measured);
                                                                                   // more tiles than slots: the dispatcher already refills
     const int S = clamp_to_horizon(std::min(kSegMaxSegments, d.H / kSegMinSteps));
@@ -287,13 +309,13 @@ int segments_for(const Dims &d, int rc, size_t n_tiles, int requested)
 
 double tile_plan_cost(const Dims &d, int rc, size_t n_tiles, int requested_segments)
 {
-    const int occ = resident_workgroups(d.NFW, rc);
+    const int occ = resident_workgroups(d.NFW, rc), kNumCUs = num_cus();
     const int S = segments_for(d, rc, n_tiles, requested_segments);
     if (S > 1 && n_tiles > (size_t)kNumCUs) {     // pinned tiles + floating segments: every CU carries the mean load, plus hand-over costs
         const bool alone = n_tiles / kNumCUs < 2;  // one pinned tile per CU: it runs without a partner most of the time
         return (double)rc * (alone ? kChunkSolo : kChunkShared)[d.NFW - 1][rc - 1] * ((double)n_tiles / kNumCUs) * kFloatOverhead;
     }
-    const long per_cu = (long)((n_tiles + 255) / 256);
+    const long per_cu = (long)((n_tiles + kNumCUs - 1) / kNumCUs);
     const long full = per_cu / occ, rem = per_cu % occ;
     auto c = [&](long resident) { return resident >= 2 ? kChunkShared[d.NFW - 1][rc - 1] : kChunkSolo[d.NFW - 1][rc - 1]; };
     return (double)rc * ((double)(full * occ) * c(occ) + (double)rem * c(rem));
@@ -314,8 +336,8 @@ int auto_chunks(const Dims &d, int requested_segments)
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t ctrl, musig, scores_local, scores_global, actions, elite, returns, costs, result, wpack, bias_h, bias_mu, bias_var,
-        nmin, ndelta, omask, kind_sel, tiles, eps_out, stamps, seg_queue, seg_flags, seg_state,
+    size_t ctrl, musig, scores_local, scores_global, actions, act_pad, elite, returns, costs, result, wpack, bias_h, bias_mu, bias_var,
+        nmin, ndelta, omask, kind_sel, etab, tiles, eps_out, stamps, seg_queue, seg_flags, seg_state,
         ms_hist, ms_sel, ms_counts, ms_best_sc, ms_best_ix, ms_part, ms_colmean, total;
 };
 
@@ -332,7 +354,7 @@ Plan make_plan(const cem_config_t *c, const Dims &d)
     pl.seg_len = (d.H + pl.n_seg - 1) / pl.n_seg;
     pl.n_seg = (d.H + pl.seg_len - 1) / pl.seg_len;
     // tiles every CU gets the same number of stay whole ("pinned"); only the remainder floats in segments
-    pl.n_pinned = pl.n_seg > 1 ? (pl.n_tiles / kNumCUs) * kNumCUs : pl.n_tiles;
+    pl.n_pinned = pl.n_seg > 1 ? (pl.n_tiles / num_cus()) * num_cus() : pl.n_tiles;
     if (c->rollout_segments > 1 && pl.n_pinned == pl.n_tiles && pl.n_seg > 1) pl.n_pinned = 0;   // an explicit request floats everything
     return pl;
 }
@@ -346,6 +368,7 @@ Layout make_layout(const cem_config_t *c, const Dims &d, size_t max_tiles)
     l.scores_local = take((size_t)d.Nloc * 4);
     l.scores_global = d.W > 1 ? take((size_t)d.N * 4) : l.scores_local;
     l.actions = take((size_t)d.N * d.H * d.A * 4);
+    l.act_pad = take((size_t)d.N * d.H * d.act_nq * 16);
     l.elite = take((size_t)d.k * 4);
     l.returns = take((size_t)d.Bloc * 4);
     l.costs = take((size_t)d.H * d.Bloc);
@@ -358,6 +381,7 @@ Layout make_layout(const cem_config_t *c, const Dims &d, size_t max_tiles)
     l.ndelta = take(CEM_U * 4);
     l.omask = take(2 * CEM_U * 4);
     l.kind_sel = take(CEM_NKIND * CEM_U * 4);
+    l.etab = take((size_t)d.E * (CEM_ET_ROWS + d.L) * CEM_U * 4);
     l.tiles = take(max_tiles * sizeof(TileDesc));
     l.eps_out = take(CEM_MAX_ACT * 4);
     l.stamps = take(std::max<size_t>(max_tiles * 4 * 8, 128) * sizeof(long long));      // [tiles][4][8] rollout stamps; [64..71] select stamps
@@ -393,9 +417,8 @@ struct Rccl {
 Rccl *rccl()
 {
     static Rccl r;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;                      // two handles may ask at once (one per env thread)
+    std::call_once(once, [] {
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (r.lib) break;
@@ -407,7 +430,7 @@ Rccl *rccl()
             r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
             if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) r.lib = nullptr;
         }
-    }
+    });
     return r.lib ? &r : nullptr;
 }
 const int kNcclFloat32 = 7;        // ncclDataType_t ncclFloat32 (rccl.h)
@@ -443,6 +466,7 @@ struct cem_planner {
     size_t sel_dyn_limit;                    // dynamic-LDS allowance of the select kernels on this handle's device
     // grow-only device scratch of the standalone ops (unfold_sequences tiles + returns, compute_objective returns + costs)
     char *scratch; size_t scratch_bytes;
+    std::vector<float> h_etab;               // host copy of RolloutParams::etab ([E][CEM_ET_ROWS + L][128]); re-uploaded whole by create / set_weights / set_normaliser
 };
 
 extern "C" {
@@ -605,9 +629,22 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
             if (f >= s.cost_lo[k] && f < s.cost_hi[k] && f < d.O) ks[(k + 1) * CEM_U + f] = ninf;
     }
     std::vector<float> mn(CEM_U, 0.f), dl(CEM_U, 1.f);
+    // the hot kernel's per-member table: identity normaliser and zero biases until set_normaliser / set_weights fill them in
+    const size_t et_rows = CEM_ET_ROWS + d.L;
+    h->h_etab.assign((size_t)d.E * et_rows * CEM_U, 0.f);
+    for (int m = 0; m < d.E; ++m) {
+        float *et = &h->h_etab[(size_t)m * et_rows * CEM_U];
+        for (int f = 0; f < CEM_U; ++f) {
+            et[CEM_ET_RDELTA * CEM_U + f] = 1.f;
+            et[CEM_ET_OBS * CEM_U + f] = om[f]; et[CEM_ET_ACT * CEM_U + f] = om[CEM_U + f];
+            et[CEM_ET_SEL0 * CEM_U + f] = ks[f]; et[CEM_ET_SEL1 * CEM_U + f] = ks[CEM_U + f];
+        }
+    }
     if (!upload(h->lay.tiles, tiles.data(), tiles.size() * sizeof(Tile6)) || !upload(h->lay.omask, om.data(), om.size() * 4) ||
         !upload(h->lay.kind_sel, ks.data(), ks.size() * 4) || !upload(h->lay.nmin, mn.data(), CEM_U * 4) ||
-        !upload(h->lay.ndelta, dl.data(), CEM_U * 4) || hipStreamSynchronize(h->stream) != hipSuccess)
+        !upload(h->lay.ndelta, dl.data(), CEM_U * 4) || !upload(h->lay.etab, h->h_etab.data(), h->h_etab.size() * 4) ||
+        hipMemsetAsync(h->ws + h->lay.act_pad, 0, (size_t)d.N * d.H * d.act_nq * 16, h->stream) != hipSuccess ||   // the padding words of the action quads are never written again
+        hipStreamSynchronize(h->stream) != hipSuccess)
         return fail(CEM_ERR_HIP);
 
     // Select kernel: scores staged in LDS when they fit.  gfx950 has 160 KB per CU and this kernel is the CU's only workgroup;
@@ -676,6 +713,16 @@ int cem_planner_set_weights(cem_planner_t *h, const float *blob, size_t n_floats
     HIPCHK(hipMemcpyAsync(h->ws + h->lay.bias_h, bh.data(), bh.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->ws + h->lay.bias_mu, bmu.data(), bmu.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->ws + h->lay.bias_var, bvar.data(), bvar.size() * 4, hipMemcpyHostToDevice, h->stream));
+    {   // the same biases as rows of the hot kernel's per-member table
+        const size_t et_rows = CEM_ET_ROWS + d.L;
+        for (int m = 0; m < d.E; ++m) {
+            float *et = &h->h_etab[(size_t)m * et_rows * CEM_U];
+            std::memcpy(et + CEM_ET_BMU * CEM_U, &bmu[(size_t)m * CEM_U], CEM_U * 4);
+            std::memcpy(et + CEM_ET_BVAR * CEM_U, &bvar[(size_t)m * CEM_U], CEM_U * 4);
+            for (int l = 0; l < d.L; ++l) std::memcpy(et + (CEM_ET_ROWS + l) * CEM_U, &bh[((size_t)m * d.L + l) * CEM_U], CEM_U * 4);
+        }
+        HIPCHK(hipMemcpyAsync(h->ws + h->lay.etab, h->h_etab.data(), h->h_etab.size() * 4, hipMemcpyHostToDevice, h->stream));
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     h->have_weights = true;
     return CEM_OK;
@@ -695,6 +742,15 @@ int cem_planner_set_normaliser(cem_planner_t *h, const float *imin, const float 
     }
     HIPCHK(hipMemcpyAsync(h->ws + h->lay.nmin, mn.data(), CEM_U * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->ws + h->lay.ndelta, dl.data(), CEM_U * 4, hipMemcpyHostToDevice, h->stream));
+    {
+        const size_t et_rows = CEM_ET_ROWS + d.L;
+        for (int m = 0; m < d.E; ++m) {
+            float *et = &h->h_etab[(size_t)m * et_rows * CEM_U];
+            std::memcpy(et + CEM_ET_NMIN * CEM_U, mn.data(), CEM_U * 4);
+            std::memcpy(et + CEM_ET_RDELTA * CEM_U, dl.data(), CEM_U * 4);
+        }
+        HIPCHK(hipMemcpyAsync(h->ws + h->lay.etab, h->h_etab.data(), h->h_etab.size() * 4, hipMemcpyHostToDevice, h->stream));
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     return CEM_OK;
 }
@@ -758,6 +814,8 @@ void fill_rollout_common(const cem_planner *h, RolloutParams &p)
     p.bias_mu = (const float *)(ws + l.bias_mu); p.bias_var = (const float *)(ws + l.bias_var);
     p.nmin = (const float *)(ws + l.nmin); p.nrdelta = (const float *)(ws + l.ndelta);
     p.omask = (const float *)(ws + l.omask); p.kind_sel = (const float *)(ws + l.kind_sel);
+    p.etab = (const float *)(ws + l.etab);
+    p.act_pad = (const f4 *)(ws + l.act_pad); p.act_pad_bytes = (uint32_t)((size_t)d.N * d.H * d.act_nq * 16); p.act_q0 = d.act_q0; p.act_nq = d.act_nq;
     p.ctrl = (const CtrlBlock *)(ws + l.ctrl);
     p.member_stride_f4 = d.member_stride_f4;
     for (int w = 0; w < 4; ++w) { p.wave_off_f4[w] = d.wave_off_f4[w]; p.wave_groups[w] = (uint32_t)d.wave_groups[w]; }
@@ -789,6 +847,7 @@ int enqueue_rollout(cem_planner *h, int it)
     SampleParams sp{}; sp.actions = (float *)(ws + l.actions); sp.musig = (const float *)(ws + l.musig);
     sp.eps_act = h->eps_act ? h->eps_act + (size_t)it * d.N * d.H * d.A : nullptr;
     sp.ctrl = (const CtrlBlock *)(ws + l.ctrl); sp.N = d.N; sp.H = d.H; sp.A = d.A; sp.it = it; sp.check_done = 1;
+    sp.act_pad = (float *)(ws + l.act_pad); sp.pad_shift = d.O - 4 * d.act_q0; sp.pad_floats = 4 * d.act_nq;
     for (int a = 0; a < d.A; ++a) { sp.lb[a] = h->cfg.act_lb[a]; sp.ub[a] = h->cfg.act_ub[a]; }
     const bool queued = h->n_seg > 1 && !h->eps_model;       // explicit eps_model tensors take the general (MODE 1) kernel
     if (queued) { sp.seg_queue = (uint32_t *)(ws + l.seg_queue); sp.seg_flags = (uint32_t *)(ws + l.seg_flags); sp.n_ready = (h->n_tiles - h->n_pinned) * (h->n_seg - 1); }
@@ -1175,6 +1234,21 @@ int cem_fill_noise(cem_planner_t *h, uint64_t seed, uint64_t call, float *eps_ac
     FillParams fp{}; fp.eps_act = eps_act_dev; fp.eps_model = eps_model_dev; fp.eps_out = eps_out_dev;
     fp.ctrl = (const CtrlBlock *)(h->ws + h->lay.ctrl); fp.I = d.I; fp.N = d.N; fp.H = d.H; fp.A = d.A; fp.B = d.Btot; fp.O = d.O;
     hipLaunchKernelGGL(cem_fill_noise_kernel, dim3(2048), dim3(256), 0, h->stream, fp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CEM_OK;
+}
+
+int cem_philox_words(cem_planner_t *h, uint64_t seed, uint64_t call, uint32_t stream, uint32_t iteration, uint32_t t, uint32_t sub,
+                     uint32_t idx0, uint32_t n, uint32_t *words_out_dev)
+{
+    if (!h || !words_out_dev || stream > 2 || iteration > 65535 || t > 65535 || sub > 65535) return CEM_ERR_INVALID_ARG;
+    if (h->in_plan) return CEM_ERR_STATE;
+    if (n == 0) return CEM_OK;
+    int st = upload_key(h, seed, call); if (st) return st;
+    WordsParams wp{}; wp.out = words_out_dev; wp.ctrl = (const CtrlBlock *)(h->ws + h->lay.ctrl);
+    wp.stream = stream; wp.it = iteration; wp.t = t; wp.sub = sub; wp.idx0 = idx0; wp.n = n;
+    hipLaunchKernelGGL(cem_philox_words_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, wp);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     return CEM_OK;

@@ -27,6 +27,16 @@
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 #define CEM_U 128            // hidden units (config/models.yaml:11)
+// rows of the per-member table RolloutParams::etab (each 128 floats, zero / identity padded)
+#define CEM_ET_NMIN 0        // scale(): inputs_min                              (transition_model.py:79-87)
+#define CEM_ET_RDELTA 1      // scale(): 1 / delta, the 1.01 rule applied
+#define CEM_ET_BMU 2         // bias of the mean head                            (mlp_ensemble.py:33)
+#define CEM_ET_BVAR 3        // bias of the variance head                        (mlp_ensemble.py:34)
+#define CEM_ET_OBS 4         // 1.0 on observation features
+#define CEM_ET_ACT 5         // 1.0 on action features
+#define CEM_ET_SEL0 6        // -inf on the features of scorer kind 0 (goal), +inf elsewhere
+#define CEM_ET_SEL1 7        // ... of the first cost kind
+#define CEM_ET_ROWS 8        // then L rows: the hidden layers' biases
 #define CEM_NG 8             // 16-feature blocks in U
 #define CEM_NKIND 5          // goal + up to 4 cost kinds
 #define CEM_PART_FLOATS (CEM_NKIND * 4 * 64)
@@ -70,6 +80,13 @@ struct RolloutParams {
     const float *nrdelta;        // [128] scale(): 1/delta (1.01 rule applied), 1 on padding
     const float *omask;          // [2][128] 1.0 on observation features / on action features, else 0
     const float *kind_sel;       // [CEM_NKIND][128] -inf where the feature belongs to scorer kind k (goal, costs...), +inf elsewhere
+    const float *etab;           // [E][CEM_ET_ROWS + L][128] everything the hot kernel's epilogue and stage prologues read per feature, one
+                                 // table per member (rows: CEM_ET_*), so that a wave addresses it as ONE buffer with a lane offset
+    const f4 *act_pad;           // [N][H][act_nq] the sampled actions again, as the feature quads of the network input that hold an
+                                 // action (quad act_q0 + i of the 128-feature input; zeros off the action features): the hot kernel
+                                 // (MODE 0) fetches a lane's four input features with one 16-byte load.  MODE 1 reads `actions`
+    uint32_t act_pad_bytes;
+    int32_t act_q0, act_nq;
     const float *s0;             // [O] broadcast or [B][O]
     const float *actions;        // [n_act][H][A]
     const float *eps_model;      // nullptr -> Philox; else this iteration's [H][Btot][O]
@@ -111,7 +128,8 @@ __device__ __forceinline__ void philox4x32_7(uint32_t &c0, uint32_t &c1, uint32_
         // one 32x32->64 multiply (v_mad_u64_u32) per product instead of a mul_hi + mul_lo pair
         const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        // hi ^ c ^ k as ONE three-input bit operation (v_bitop3_b32, truth table 0x96 = xor3): left alone the compiler emits two v_xor
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
@@ -124,43 +142,80 @@ __device__ __forceinline__ PhiloxKey cem_key(const CtrlBlock *ctrl)
     PhiloxKey k; k.k0 = ctrl->seed_lo; k.k1 = ctrl->seed_hi ^ ctrl->call_hi; k.c3 = ctrl->call_lo; return k;
 }
 
-__device__ __forceinline__ f4 cem_normal4(uint32_t idx, uint32_t t, uint32_t it, uint32_t sub, uint32_t stream, const PhiloxKey key)
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define CEM_BM_RSCALE (-1.3862943611198906f)     // -2 ln 2: r = sqrt(-2 ln u) = sqrt(CEM_BM_RSCALE * log2 u)
+
+// Four standard normals of counter (idx, t, it, sub, stream): Philox words -> uniforms -> Box-Muller.
+//   u = fl32(fl32(word) * 2^-32 + 2^-33)  (v_cvt_f32_u32 + one fma, the pair of a radius / angle as one v_pk_fma_f32): in (0, 1],
+//       never 0, spacing 2^-24 near 1 and finer towards 0 (largest radius sqrt(66 ln 2) = 6.76)
+//   z0 = r(u0) cos(2 pi u1), z1 = r(u0) sin(2 pi u1), z2 = r(u2) cos(2 pi u3), z3 = r(u2) sin(2 pi u3),  r(u) = sqrt(rscale * log2 u)
+// on v_log_f32 (log2), v_sqrt_f32, v_sin_f32 / v_cos_f32 (argument in revolutions).  rscale = CEM_BM_RSCALE; 0 gives four zeros
+// exactly (sampling_propagation False costs no extra multiply).  tests/test_gpu_rng.py restates this in numpy (known answers).
+__device__ __forceinline__ f4 cem_normal4(uint32_t idx, uint32_t t, uint32_t it, uint32_t sub, uint32_t stream, const PhiloxKey key,
+                                          const float rscale = CEM_BM_RSCALE)
 {
     uint32_t c0 = idx, c1 = t | (it << 16), c2 = sub | (stream << 16), c3 = key.c3;
     philox4x32_7(c0, c1, c2, c3, key.k0, key.k1);
-    // 23-bit uniforms in (0,1): ((x>>9)+0.5) * 2^-23 is exact in fp32
-    const float u0 = ((float)(c0 >> 9) + 0.5f) * 1.1920928955078125e-07f;
-    const float u1 = ((float)(c1 >> 9) + 0.5f) * 1.1920928955078125e-07f;
-    const float u2 = ((float)(c2 >> 9) + 0.5f) * 1.1920928955078125e-07f;
-    const float u3 = ((float)(c3 >> 9) + 0.5f) * 1.1920928955078125e-07f;
-    // r = sqrt(-2 ln u) with v_log_f32 (log2); angle in revolutions for v_sin/v_cos
-    const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
-    const float rb = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
-    f4 z;
-    z[0] = ra * __builtin_amdgcn_cosf(u1);
-    z[1] = ra * __builtin_amdgcn_sinf(u1);
-    z[2] = rb * __builtin_amdgcn_cosf(u3);
-    z[3] = rb * __builtin_amdgcn_sinf(u3);
-    return z;
+    const f2 h = {1.1641532182693481e-10f, 1.1641532182693481e-10f};       // 2^-33
+    const f2 ur = __builtin_elementwise_fma((f2){(float)c0, (float)c2}, (f2){2.3283064365386963e-10f, 2.3283064365386963e-10f}, h);   // radii
+    const f2 ua = __builtin_elementwise_fma((f2){(float)c1, (float)c3}, (f2){2.3283064365386963e-10f, 2.3283064365386963e-10f}, h);   // angles
+    const f2 l = (f2){__builtin_amdgcn_logf(ur[0]), __builtin_amdgcn_logf(ur[1])} * rscale;
+    const float ra = __builtin_amdgcn_sqrtf(l[0]), rb = __builtin_amdgcn_sqrtf(l[1]);
+    const f2 za = (f2){__builtin_amdgcn_cosf(ua[0]), __builtin_amdgcn_sinf(ua[0])} * ra;
+    const f2 zb = (f2){__builtin_amdgcn_cosf(ua[1]), __builtin_amdgcn_sinf(ua[1])} * rb;
+    return (f4){za[0], za[1], zb[0], zb[1]};
 }
 
 // tf.math.softplus.  Eigen evaluates x (x > 13.94), exp(x) (x < -13.94), log1p(exp(x)) otherwise;
-// all three branches are the one function max(x,0) + log1p(exp(-|x|)) to within 1e-6 relative, computed here
-// branch-free: t = exp(-|x|) on v_exp_f32, log1p(t) = 2 atanh(t/(2+t)) as an odd series in z = t/(2+t) <= 1/3
-// (truncation < 2e-8).  Measured against the fp64 oracle in tests/test_gpu_parity.py.
+// all three branches are the one function max(x,0) + log1p(exp(-|x|)) to within 2e-6 relative, computed here
+// branch-free: t = exp(-|x|) on v_exp_f32, log1p(t) = 2 atanh(z), z = t/(2+t) <= 1/3, with 2 atanh(z)/z as a degree-4 minimax
+// polynomial in z^2 on [0, 1/9] (relative error 4e-9; the factor 2 is folded into the coefficients).  Written on four values
+// at a time: beside fp32 MFMAs a packed v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 costs what ONE scalar VALU instruction costs
+// (scripts/mfma_microbench5.hip), so the element chains of the rollout epilogue run two elements per instruction.  The scalar
+// form below is the same sequence of operations (bit-identical).  Measured against the fp64 oracle in tests/test_gpu_parity.py.
+#define CEM_SP_C4 0.28191542625427246f
+#define CEM_SP_C3 0.27957665920257568f
+#define CEM_SP_C2 0.4002511501312256f
+#define CEM_SP_C1 0.66666311025619507f
+#define CEM_SP_C0 2.0f
+__device__ __forceinline__ f4 cem_splat4(const float v) { return (f4){v, v, v, v}; }
+// a - b on four values as two v_pk_add_f32 with the second operand negated: the compiler scalarises a <2 x float> fsub into
+// v_sub_f32 (only packed add / mul / fma are selected), and folds fma(b, -1, a) back into that fsub.  Same result bit for bit.
+__device__ __forceinline__ f4 cem_sub4(const f4 a, const f4 b)
+{
+    f2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"((f2){a[0], a[1]}), "v"((f2){b[0], b[1]}));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"((f2){a[2], a[3]}), "v"((f2){b[2], b[3]}));
+    return (f4){lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ f4 cem_softplus4(const f4 x)
+{
+    f4 t, rc, mx;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = __builtin_amdgcn_exp2f(-1.4426950408889634f * __builtin_fabsf(x[r]));
+    const f4 den = t + 2.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rc[r] = __builtin_amdgcn_rcpf(den[r]);
+    const f4 z = t * rc;
+    const f4 z2 = z * z;
+    f4 q = __builtin_elementwise_fma(cem_splat4(CEM_SP_C4), z2, cem_splat4(CEM_SP_C3));
+    q = __builtin_elementwise_fma(q, z2, cem_splat4(CEM_SP_C2));
+    q = __builtin_elementwise_fma(q, z2, cem_splat4(CEM_SP_C1));
+    q = __builtin_elementwise_fma(q, z2, cem_splat4(CEM_SP_C0));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mx[r] = fmaxf(x[r], 0.f);
+    return __builtin_elementwise_fma(z, q, mx);
+}
 __device__ __forceinline__ float cem_softplus(float x)
 {
     const float t = __builtin_amdgcn_exp2f(-1.4426950408889634f * __builtin_fabsf(x));
-    const float z = t * __builtin_amdgcn_rcpf(2.0f + t);
+    const float z = t * __builtin_amdgcn_rcpf(t + 2.0f);
     const float z2 = z * z;
-    float q = 0.07692307692307693f;                       // 1/13
-    q = __builtin_fmaf(q, z2, 0.09090909090909091f);      // 1/11
-    q = __builtin_fmaf(q, z2, 0.1111111111111111f);
-    q = __builtin_fmaf(q, z2, 0.14285714285714285f);
-    q = __builtin_fmaf(q, z2, 0.2f);
-    q = __builtin_fmaf(q, z2, 0.3333333333333333f);
-    q = __builtin_fmaf(q, z2, 1.0f);
-    return __builtin_fmaf(2.0f * z, q, fmaxf(x, 0.f));
+    float q = __builtin_fmaf(CEM_SP_C4, z2, CEM_SP_C3);
+    q = __builtin_fmaf(q, z2, CEM_SP_C2);
+    q = __builtin_fmaf(q, z2, CEM_SP_C1);
+    q = __builtin_fmaf(q, z2, CEM_SP_C0);
+    return __builtin_fmaf(z, q, fmaxf(x, 0.f));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -305,9 +360,29 @@ __device__ __forceinline__ void cem_st_coherent(__amdgpu_buffer_rsrc_t rsrc, int
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cem_u4, v), rsrc, byte_off, 0, CEM_AUX_SC1);
 }
 
+__device__ __forceinline__ f4 cem_ld_tab(__amdgpu_buffer_rsrc_t rs, int voff, int row_bytes)
+{
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, row_bytes, 0));
+}
+
+// closest_distance terms (safety_gym.py:188-192) of four features of one batch row, folded into the running minima of the goal
+// kind and of the first cost kind: lid = clip(D - D (1 - x), 0, D); a feature outside a kind's slice has sel = +inf (no effect),
+// one inside has sel = -inf.  (The goal kind in observe_goal_dist mode is redone by the caller: rare, kept out of the hot block.)
+__device__ __forceinline__ void cem_scorer_terms(const f4 sn, const float D, const f4 sel0, const f4 sel1, float &pm0, float &pm1)
+{
+    const f4 lr = cem_sub4(cem_splat4(D), D * cem_sub4(cem_splat4(1.0f), sn));       // D - D (1 - x), each operation rounded
+    f4 lid;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lid[r] = __builtin_amdgcn_fmed3f(lr[r], 0.f, D);          // = min(max(lr, 0), D) for D >= 0
+    pm0 = fminf(fminf(pm0, fmaxf(lid[0], sel0[0])), fmaxf(lid[1], sel0[1]));
+    pm0 = fminf(fminf(pm0, fmaxf(lid[2], sel0[2])), fmaxf(lid[3], sel0[3]));
+    pm1 = fminf(fminf(pm1, fmaxf(lid[0], sel1[0])), fmaxf(lid[1], sel1[1]));
+    pm1 = fminf(fminf(pm1, fmaxf(lid[2], sel1[2])), fmaxf(lid[3], sel1[3]));
+}
+
 // One tile for steps [t_begin, t_end) of the horizon.  SEG false: the whole horizon (t_begin = 0, t_end = H).  SEG true: one
-// segment of it; what a tile carries across a segment boundary (state registers, its next layer-0 input blocks, wave 0's
-// reward / done bookkeeping) goes through p.seg_state, so any workgroup on any CU can run the tile's next segment and the
+// segment of it; what a tile carries across a segment boundary (state registers, its next layer-0 input blocks, the bookkeeping
+// wave's reward / done state) goes through p.seg_state, so any workgroup on any CU can run the tile's next segment and the
 // result is bit-identical to the unsegmented run.
 template <int RC, int NFW, int MODE, bool SEG>
 __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *smem, const int tile_idx, const int t_begin, const int t_end)
@@ -318,6 +393,9 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
     const int j = lane & 15, q = lane >> 4;
     const TileDesc td = p.tiles[tile_idx];
     const bool resumed = SEG && t_begin > 0;
+    // The reward / cost / done bookkeeping of a tile's rows is one wave's extra work (about 70 VALU instructions per step next to
+    // 330).  Which wave does it depends on the tile, so that the tiles sharing a CU do not all load the same SIMD with it.
+    const int wbk = (tile_idx + (tile_idx >> 8)) & 3;
     // this tile's slot of the hand-over buffer as a buffer resource: [2*NFW*RC][256 threads] f4 + [64 lanes] f4
     const __amdgpu_buffer_rsrc_t seg_rs = __builtin_amdgcn_make_buffer_rsrc(
         SEG ? const_cast<f4 *>(p.seg_state + (size_t)(tile_idx - p.n_pinned) * (2 * NFW * RC * 256 + 64)) : const_cast<f4 *>(p.wpack), 0,
@@ -327,17 +405,19 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
     float *part = reinterpret_cast<float *>(smem + 2 * XB);
     int xw = 0;                                          // LDS buffer the current stage's outputs go to
     const PhiloxKey key = cem_key(p.ctrl);
+    const float rscale = p.sampling ? CEM_BM_RSCALE : 0.0f;     // sampling_propagation False: the model noise is exactly 0
 
+    // descriptor inputs made provably wave-uniform (the tile descriptor load and the wave id are uniform in fact)
+    const int member_u = __builtin_amdgcn_readfirstlane(td.member);
     WRing wq;
-    {
-        // descriptor inputs made provably wave-uniform (the tile descriptor load and the wave id are uniform in fact)
-        const int member_u = __builtin_amdgcn_readfirstlane(td.member);
-        wq.init(p.wpack + (size_t)member_u * p.member_stride_f4 + p.wave_off_f4[w], lane, (int)p.wave_groups[w]);
-    }
+    wq.init(p.wpack + (size_t)member_u * p.member_stride_f4 + p.wave_off_f4[w], lane, (int)p.wave_groups[w]);
 
-    const float *bias_h = p.bias_h + (size_t)td.member * p.L * CEM_U;
-    const float *bias_mu = p.bias_mu + (size_t)td.member * CEM_U;
-    const float *bias_var = p.bias_var + (size_t)td.member * CEM_U;
+    // the member's feature tables as one buffer: row r at byte r * 512, this lane's feature quad f0 = 16 (w + 4 i) + 4 q at
+    // byte 4 f0 of a row.  No 64-bit address arithmetic and no address registers besides tab_v.
+    const __amdgpu_buffer_rsrc_t et_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.etab + (size_t)member_u * (CEM_ET_ROWS + p.L) * CEM_U), 0, (CEM_ET_ROWS + p.L) * CEM_U * 4, 0x00020000);
+    const int tab_v = 64 * w + 16 * q;                   // + 256 i
+    const int bias_v = 128 * w + 16 * q;                 // the wave's output blocks 2w (and 2w+1: + 64) of a hidden layer
 
     // ---- state registers: wave w owns input feature blocks Fo = w + 4 i --------------------------------
     f4 s[NFW][RC];
@@ -360,35 +440,54 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
         }
     }
 
-    // per-chunk action-sequence row of this lane's batch row (64-bit address arithmetic once, not every step)
+    // this lane's actions.  MODE 0: the padded quad layout (one 16-byte buffer load per unit and step, the step in the scalar
+    // offset); MODE 1 (caller-supplied action tensors): the natural [n][H][A] layout, element by element.
+    const __amdgpu_buffer_rsrc_t act_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<f4 *>(p.act_pad), 0, MODE == 0 ? p.act_pad_bytes : 0u, 0x00020000);
+    int actv[NFW][RC];
     const float *actrow[RC];
 #pragma unroll
-    for (int c = 0; c < RC; ++c) actrow[c] = p.actions + (size_t)(td.act_base + slotc[c]) * H * A;
+    for (int c = 0; c < RC; ++c) {
+        actrow[c] = p.actions + (size_t)(td.act_base + slotc[c]) * H * A;
+#pragma unroll
+        for (int i = 0; i < NFW; ++i) {
+            int qi = 4 * (w + 4 * i) + q - p.act_q0;
+            qi = qi < 0 ? 0 : (qi >= p.act_nq ? p.act_nq - 1 : qi);      // a quad without action features: any valid quad (its mask is 0)
+            actv[i][c] = ((td.act_base + slotc[c]) * H * p.act_nq + qi) * 16;
+        }
+    }
+#define CEM_LOAD_ACT(DST, I_, C_, TN_) do { \
+        if (MODE == 0) DST = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(act_rs, actv[I_][C_], (TN_) * p.act_nq * 16, 0)); \
+        else { _Pragma("unroll") for (int r = 0; r < 4; ++r) { \
+            int af = 16 * (w + 4 * (I_)) + 4 * q + r - O; af = af < 0 ? 0 : (af >= A ? A - 1 : af); \
+            DST[r] = actrow[C_][(TN_) * A + af]; } } } while (0)
 
-    // score owner (wave 0, lane == row slot)
+    // score owner (wave wbk, lane == row slot)
     float d_prev = 0.f, c_prev = 0.f, cum = 0.f;
     bool done = false;
     const int nk = 1 + p.sc.n_cost;
+    const float csz[4] = {p.sc.cost_size[0], p.sc.cost_size[1], p.sc.cost_size[2], p.sc.cost_size[3]};
+    const float ind_cap = p.sc.indicator ? 1.0f : __builtin_inff(), clipv = p.sc.reward_clip > 0.f ? p.sc.reward_clip : __builtin_inff();
+    const __amdgpu_buffer_rsrc_t cost_rs = __builtin_amdgcn_make_buffer_rsrc(p.costs, 0, p.costs ? (uint32_t)(H * p.Bloc) : 0u, 0x00020000);
 
-    // reward / cost / done bookkeeping of step T_ from the scorer terms in `part` (rows of the tile on wave 0's lanes);
-    // T_ = -1 only initialises d_prev / c_prev from s_0
-#define CEM_BOOKKEEP(T_) do { if (w == 0) { \
-        float dn = fminf(fminf(part[0 * 64 + lane], part[1 * 64 + lane]), fminf(part[2 * 64 + lane], part[3 * 64 + lane])); \
+    // reward / cost / done bookkeeping of step T_ from the scorer terms in `part` (rows of the tile on the bookkeeping wave's
+    // lanes); T_ = -1 only initialises d_prev / c_prev from s_0
+#define CEM_PART_MIN4(K_) fminf(fminf(part[((K_) * 4 + 0) * 64 + lane], part[((K_) * 4 + 1) * 64 + lane]), \
+                                fminf(part[((K_) * 4 + 2) * 64 + lane], part[((K_) * 4 + 3) * 64 + lane]))
+#define CEM_BOOKKEEP(T_) do { if (w == wbk) { \
+        const float dn = CEM_PART_MIN4(0); \
         float cn = 0.f; \
-        for (int k = 1; k < nk; ++k) { \
-            const float dk = fminf(fminf(part[(k * 4 + 0) * 64 + lane], part[(k * 4 + 1) * 64 + lane]), \
-                                   fminf(part[(k * 4 + 2) * 64 + lane], part[(k * 4 + 3) * 64 + lane])); \
-            cn = cn + ((dk <= p.sc.cost_size[k - 1]) ? 1.0f : 0.0f); } \
-        if (p.sc.indicator) cn = cn > 0.f ? 1.0f : 0.0f; \
+        _Pragma("unroll") for (int k = 1; k < CEM_NKIND; ++k) \
+            if (k < nk) { const float dk = CEM_PART_MIN4(k); cn = cn + ((dk <= csz[k - 1]) ? 1.0f : 0.0f); } \
+        cn = fminf(cn, ind_cap);                                   /* constrain_indicator: cost > 0 -> 1 (cn is a count) */ \
         if ((T_) >= 0) { \
             const bool ga = d_prev <= p.sc.goal_thresh;                                   /* safety_gym.py:116 */ \
             float r = (d_prev - dn) * p.sc.reward_distance + (ga ? 1.0f : 0.0f) * p.sc.reward_goal; \
-            if (p.sc.reward_clip > 0.f) r = fminf(fmaxf(r, -p.sc.reward_clip), p.sc.reward_clip); \
+            r = fminf(fmaxf(r, -clipv), clipv);                        /* reward_clip (safety_gym.py:141); +inf: none */ \
             if (p.variant == 1) {                                                         /* safe_cem_mpc.py:86-93 */ \
                 done = done || ga; \
                 const float nd = done ? 0.0f : 1.0f; \
                 const float cst = c_prev * nd; \
-                if (p.costs && lane < td.cnt) p.costs[(size_t)(T_) * p.Bloc + td.row_base + lane] = (uint8_t)cst; \
+                if (p.costs && lane < td.cnt) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)cst, cost_rs, td.row_base + lane, __builtin_amdgcn_readfirstlane((T_) * p.Bloc), 0); \
                 cum = cum + r * nd; \
             } else {                                                                      /* mpc_policy.py:34-37 */ \
                 const float nd = done ? 0.0f : 1.0f; \
@@ -397,10 +496,45 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
             } } \
         d_prev = dn; c_prev = cn; } } while (0)
 
+    // min over the 4 lane rows that hold different features of the same batch row, for TWO scorer kinds at once: one row swap
+    // puts kind KA's partial minima into the even lane rows and kind KA+1's into the odd ones, one half swap finishes both (two
+    // VALU swaps + two v_min for a pair of kinds, no LDS).  Lane rows 0 / 2 then hold kind KA, rows 1 / 3 kind KA + 1 (PAIRED)
+    // and every row stores its kind's value for its batch row (rows q and q + 2 store the same word).
+#define CEM_PAIR_MIN_STORE(KA, VA, VB, PAIRED, C_) do { \
+        const auto r16_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(VA), __float_as_uint(VB), false, false); \
+        const uint32_t m16_ = __float_as_uint(fminf(__uint_as_float(r16_[0]), __uint_as_float(r16_[1]))); \
+        const auto r32_ = __builtin_amdgcn_permlane32_swap(m16_, m16_, false, false); \
+        part[(((KA) + ((PAIRED) ? (q & 1) : 0)) * 4 + w) * 64 + 16 * (C_) + j] = fminf(__uint_as_float(r32_[0]), __uint_as_float(r32_[1])); \
+    } while (0)
+
+    // scorer kinds beyond (goal, first cost kind) and the observe_goal_dist form of the goal kind: rare, kept out of the hot block
+#define CEM_RARE_KINDS_AND_STORE() do { \
+        if (p.sc.goal_mode) {                                 /* squeeze(relu(goal_dist)), safety_gym.py:172-174 */ \
+            _Pragma("unroll") for (int c = 0; c < RC; ++c) pm[0][c] = __builtin_inff(); \
+            _Pragma("unroll") for (int i = 0; i < NFW; ++i) { \
+                const f4 selg = cem_ld_tab(et_rs, tab_v + 256 * i, CEM_ET_SEL0 * 512); \
+                _Pragma("unroll") for (int c = 0; c < RC; ++c) \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) pm[0][c] = fminf(pm[0][c], fmaxf(fmaxf(s[i][c][r], 0.f), selg[r])); } } \
+        _Pragma("unroll") for (int c = 0; c < RC; ++c) CEM_PAIR_MIN_STORE(0, pm[0][c], pm[1][c], true, c); \
+        if (nk > 2) {                                         /* vases + hazards + pillars + gremlins all constrained */ \
+            float pk[3][RC]; \
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) _Pragma("unroll") for (int c = 0; c < RC; ++c) pk[k][c] = __builtin_inff(); \
+            _Pragma("unroll") for (int i = 0; i < NFW; ++i) { \
+                const int f0 = 16 * (w + 4 * i) + 4 * q; \
+                _Pragma("unroll") for (int k = 2; k < CEM_NKIND; ++k) if (k < nk) { \
+                    const f4 selk = *reinterpret_cast<const f4 *>(p.kind_sel + k * CEM_U + f0); \
+                    _Pragma("unroll") for (int c = 0; c < RC; ++c) \
+                        _Pragma("unroll") for (int r = 0; r < 4; ++r) { \
+                            const float lid = fminf(fmaxf(p.sc.D - p.sc.D * (1.0f - s[i][c][r]), 0.f), p.sc.D); \
+                            pk[k - 2][c] = fminf(pk[k - 2][c], fmaxf(lid, selk[r])); } } } \
+            _Pragma("unroll") for (int c = 0; c < RC; ++c) { \
+                CEM_PAIR_MIN_STORE(2, pk[0][c], pk[1][c], true, c); \
+                if (nk > 4) CEM_PAIR_MIN_STORE(4, pk[2][c], pk[2][c], false, c); } } } while (0)
+
     f4 hB[CEM_NG][RC];
     if (resumed) {
         // the tile's state as its previous segment left it: the wave's own layer-0 input blocks go back into registers and
-        // into the LDS exchange buffer (the barrier inside the first stage publishes them), wave 0 takes the bookkeeping back
+        // into the LDS exchange buffer (the barrier inside the first stage publishes them), the bookkeeping wave takes its state back
 #pragma unroll
         for (int i = 0; i < NFW; ++i)
 #pragma unroll
@@ -410,13 +544,45 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
                 *reinterpret_cast<f4 *>(smem + ((c * CEM_NG + w + 4 * i) * 64 + lane) * 16) = x;
             }
         xw = XB;
-        if (w == 0) {
+        if (w == wbk) {
             const f4 b = cem_ld_coherent(seg_rs, (2 * NFW * RC * 256 + lane) * 16);
             d_prev = b[0]; c_prev = b[1]; cum = b[2]; done = b[3] != 0.f;
         }
+    } else {
+        // ---- prologue: the scaled input of step 0, x_0 = scale(concat[s_0, a_0]) (transition_model.py:70-72,79-87), and the
+        //      scorer terms of s_0 (d_prev / c_prev of the first reward, safety_gym.py:62-66).  No network evaluation.
+        float pm[2][RC];
+#pragma unroll
+        for (int c = 0; c < RC; ++c) { pm[0][c] = __builtin_inff(); pm[1][c] = __builtin_inff(); }
+#pragma unroll
+        for (int i = 0; i < NFW; ++i) {
+            const int tv = tab_v + 256 * i;
+            const f4 mn4 = cem_ld_tab(et_rs, tv, CEM_ET_NMIN * 512), rd4 = cem_ld_tab(et_rs, tv, CEM_ET_RDELTA * 512);
+            const f4 isact4 = cem_ld_tab(et_rs, tv, CEM_ET_ACT * 512);
+            const f4 sel0 = cem_ld_tab(et_rs, tv, CEM_ET_SEL0 * 512), sel1 = cem_ld_tab(et_rs, tv, CEM_ET_SEL1 * 512);
+#pragma unroll
+            for (int c = 0; c < RC; ++c) {
+                f4 act4; CEM_LOAD_ACT(act4, i, c, 0);
+                const f4 sn = s[i][c];
+                if (MODE == 1) {
+                    const int slot = 16 * c + j, f0 = 16 * (w + 4 * i) + 4 * q;
+                    if (p.traj && slot < td.cnt) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (f0 + r < O) p.traj[((size_t)(td.row_base + slot) * (H + 1)) * O + f0 + r] = sn[r];
+                    }
+                }
+                cem_scorer_terms(sn, p.sc.D, sel0, sel1, pm[0][c], pm[1][c]);
+                const f4 x = cem_sub4(__builtin_elementwise_fma(isact4, act4, sn), mn4) * rd4;      // s is 0 off the observation features
+                *reinterpret_cast<f4 *>(smem + ((c * CEM_NG + w + 4 * i) * 64 + lane) * 16) = x;
+                hB[i][c] = x;
+            }
+        }
+        CEM_RARE_KINDS_AND_STORE();
+        xw = XB;
     }
-    f4 nb0 = *reinterpret_cast<const f4 *>(bias_h + 16 * (2 * w) + 4 * q);            // layer-0 bias, own blocks 2w, 2w+1
-    f4 nb1 = *reinterpret_cast<const f4 *>(bias_h + 16 * (2 * w + 1) + 4 * q);
+    f4 nb0 = cem_ld_tab(et_rs, bias_v, CEM_ET_ROWS * 512);                              // layer-0 bias, own blocks 2w, 2w+1
+    f4 nb1 = cem_ld_tab(et_rs, bias_v + 64, CEM_ET_ROWS * 512);
 #ifdef CEM_STAMPS
     long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev_ = (long long)__builtin_amdgcn_s_memtime();
@@ -425,150 +591,125 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
     st_[7] = tprev_;
 #endif
 
-    for (int t = resumed ? t_begin : -1; t < t_end; ++t) {
-        if (t >= 0) {
-            // ---- dense layers: h = relu(h W + b)  (mlp_ensemble.py:18-22).  The accumulators start at the bias
-            // (x W + b with b added first: same sum, one rounding order apart); the bias of the NEXT layer is requested a
-            // whole stage ahead of its use.  Layer 0 is peeled out of the loop: with both stage shapes inside one runtime
-            // loop the compiler merges their weight-ring registers at the join with moves behind an s_waitcnt vmcnt(0),
-            // i.e. drains the prefetch ring once per step.
+    for (int t = t_begin; t < t_end; ++t) {
+        // ---- dense layers: h = relu(h W + b)  (mlp_ensemble.py:18-22).  The accumulators start at the bias
+        // (x W + b with b added first: same sum, one rounding order apart); the bias of the NEXT layer is requested a
+        // whole stage ahead of its use.  Layer 0 is peeled out of the loop: with both stage shapes inside one runtime
+        // loop the compiler merges their weight-ring registers at the join with moves behind an s_waitcnt vmcnt(0),
+        // i.e. drains the prefetch ring once per step.
 #define CEM_RELU_PUBLISH() do { \
-                _Pragma("unroll") for (int c = 0; c < RC; ++c) { \
-                    f4 h0 = acc0[c], h1 = acc1[c]; \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) { h0[r] = fmaxf(h0[r], 0.f); h1[r] = fmaxf(h1[r], 0.f); } \
-                    *reinterpret_cast<f4 *>(smem + xw + ((c * CEM_NG + 2 * w) * 64 + lane) * 16) = h0; \
-                    *reinterpret_cast<f4 *>(smem + xw + ((c * CEM_NG + 2 * w + 1) * 64 + lane) * 16) = h1; \
-                    hB[0][c] = h0; hB[1][c] = h1;         /* own blocks of the next stage: no LDS round trip */ \
-                } \
-                xw ^= XB; } while (0)
+            _Pragma("unroll") for (int c = 0; c < RC; ++c) { \
+                f4 h0 = acc0[c], h1 = acc1[c]; \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) { h0[r] = fmaxf(h0[r], 0.f); h1[r] = fmaxf(h1[r], 0.f); } \
+                *reinterpret_cast<f4 *>(smem + xw + ((c * CEM_NG + 2 * w) * 64 + lane) * 16) = h0; \
+                *reinterpret_cast<f4 *>(smem + xw + ((c * CEM_NG + 2 * w + 1) * 64 + lane) * 16) = h1; \
+                hB[0][c] = h0; hB[1][c] = h1;         /* own blocks of the next stage: no LDS round trip */ \
+            } \
+            xw ^= XB; } while (0)
 #define CEM_NEXT_BIAS(LN) do { \
-                nb0 = *reinterpret_cast<const f4 *>(bias_h + (LN) * CEM_U + 16 * (2 * w) + 4 * q); \
-                nb1 = *reinterpret_cast<const f4 *>(bias_h + (LN) * CEM_U + 16 * (2 * w + 1) + 4 * q); } while (0)
-            {
-                f4 acc0[RC], acc1[RC];
+            nb0 = cem_ld_tab(et_rs, bias_v, (CEM_ET_ROWS + (LN)) * 512); \
+            nb1 = cem_ld_tab(et_rs, bias_v + 64, (CEM_ET_ROWS + (LN)) * 512); } while (0)
+        {
+            f4 acc0[RC], acc1[RC];
 #pragma unroll
-                for (int c = 0; c < RC; ++c) { acc0[c] = nb0; acc1[c] = nb1; }
-                CEM_NEXT_BIAS(p.L > 1 ? 1 : 0);
-                // stage input = previous stage's output buffer = xw ^ XB (the previous stage toggled xw after writing)
-                cem_mfma_stage<RC, 4 * NFW, NFW, true, CEM_X_EXCHANGE>(acc0, acc1, hB, wq, smem, xw ^ XB, lane, w);
-                if (!(resumed && t == t_begin)) CEM_BOOKKEEP(t - 1);   // the barrier inside the stage published step t-1's scorer terms (a resumed segment took them from seg_state)
-                CEM_RELU_PUBLISH();
-                CEM_STAMP(0);
-            }
-            for (int l = 1; l < p.L; ++l) {
-                f4 acc0[RC], acc1[RC];
+            for (int c = 0; c < RC; ++c) { acc0[c] = nb0; acc1[c] = nb1; }
+            CEM_NEXT_BIAS(p.L > 1 ? 1 : 0);
+            // stage input = previous stage's output buffer = xw ^ XB (the previous stage toggled xw after writing)
+            cem_mfma_stage<RC, 4 * NFW, NFW, true, CEM_X_EXCHANGE>(acc0, acc1, hB, wq, smem, xw ^ XB, lane, w);
+            if (!(resumed && t == t_begin)) CEM_BOOKKEEP(t - 1);   // the barrier inside the stage published step t-1's scorer terms (a resumed segment took them from seg_state)
+            CEM_RELU_PUBLISH();
+            CEM_STAMP(0);
+        }
+        for (int l = 1; l < p.L; ++l) {
+            f4 acc0[RC], acc1[RC];
 #pragma unroll
-                for (int c = 0; c < RC; ++c) { acc0[c] = nb0; acc1[c] = nb1; }
-                CEM_NEXT_BIAS(l + 1 < p.L ? l + 1 : 0);
-                cem_mfma_stage<RC, CEM_NG, 2, false, CEM_X_EXCHANGE>(acc0, acc1, hB, wq, smem, xw ^ XB, lane, w);
-                CEM_RELU_PUBLISH();
-                CEM_STAMP(1);
-            }
+            for (int c = 0; c < RC; ++c) { acc0[c] = nb0; acc1[c] = nb1; }
+            CEM_NEXT_BIAS(l + 1 < p.L ? l + 1 : 0);
+            cem_mfma_stage<RC, CEM_NG, 2, false, CEM_X_EXCHANGE>(acc0, acc1, hB, wq, smem, xw ^ XB, lane, w);
+            CEM_RELU_PUBLISH();
+            CEM_STAMP(1);
+        }
 #undef CEM_RELU_PUBLISH
 #undef CEM_NEXT_BIAS
-        }
 
         // ---- heads (mlp_ensemble.py:33-34,189-193), state update (transition_model.py:75), scorer partials
         //      (safety_gym.py:188-192) and the next scaled input (transition_model.py:70-72,79-87).
-        // A lone wave runs this between the MFMA stages, so it is written as ONE branch-free basic block: 4*RC*NFW
-        // independent element chains + RC*NFW Philox chains give the scheduler the ILP to hide VALU / transcendental
-        // latency (with per-chunk uniform branches it ran latency-bound at ~12 cycles per instruction).  Per-lane
-        // predicates come from per-feature float tables (omask, kind_sel), not from lane-mask SGPR pairs.
-        float pm[CEM_NKIND][RC];
+        // A lone wave runs this between the MFMA stages, so it is written as ONE branch-free basic block of independent element
+        // chains, FOUR elements (a lane's feature quad) at a time: the multiplies / adds / fmas compile to packed
+        // v_pk_{mul,add,fma}_f32, which beside fp32 MFMAs cost what one scalar VALU instruction costs (2 elements each).
+        // Per-lane predicates come from per-feature float tables (rows of etab), not from lane-mask SGPR pairs.
+        float pm[2][RC];
 #pragma unroll
-        for (int k = 0; k < CEM_NKIND; ++k)
-#pragma unroll
-            for (int c = 0; c < RC; ++c) pm[k][c] = __builtin_inff();
+        for (int c = 0; c < RC; ++c) { pm[0][c] = __builtin_inff(); pm[1][c] = __builtin_inff(); }
         const int tn = (t + 1 < H) ? t + 1 : H - 1;
-        const float live = (t >= 0) ? 1.0f : 0.0f;          // prologue: no heads, the "update" adds exactly 0
-        const float sampling = p.sampling ? 1.0f : 0.0f;
-        const float goalm = p.sc.goal_mode ? 1.0f : 0.0f;
         f4 xown[NFW][RC];
 
 #pragma unroll
         for (int i = 0; i < NFW; ++i) {
             const int Fo = w + 4 * i;                  // < 4*NFW: every such block is an input block (zero padded)
-            const int f0 = 16 * Fo + 4 * q;
+            const int tv = tab_v + 256 * i;
             // everything the epilogue needs from memory is requested BEFORE the MFMA stage
-            const f4 mn4 = *reinterpret_cast<const f4 *>(p.nmin + f0);
-            const f4 rd4 = *reinterpret_cast<const f4 *>(p.nrdelta + f0);
-            const f4 bm = *reinterpret_cast<const f4 *>(bias_mu + f0);
-            const f4 bv = *reinterpret_cast<const f4 *>(bias_var + f0);
-            const f4 om4 = *reinterpret_cast<const f4 *>(p.omask + f0) * live;                 // 1 on observation features
-            const f4 isact4 = *reinterpret_cast<const f4 *>(p.omask + CEM_U + f0);            // 1 on action features
-            const f4 sel0 = *reinterpret_cast<const f4 *>(p.kind_sel + f0);                    // -inf on goal features, +inf elsewhere
-            const f4 sel1 = *reinterpret_cast<const f4 *>(p.kind_sel + CEM_U + f0);            // first cost kind
+            const f4 mn4 = cem_ld_tab(et_rs, tv, CEM_ET_NMIN * 512), rd4 = cem_ld_tab(et_rs, tv, CEM_ET_RDELTA * 512);
+            const f4 bm = cem_ld_tab(et_rs, tv, CEM_ET_BMU * 512), bv = cem_ld_tab(et_rs, tv, CEM_ET_BVAR * 512);
+            const f4 om4 = cem_ld_tab(et_rs, tv, CEM_ET_OBS * 512), isact4 = cem_ld_tab(et_rs, tv, CEM_ET_ACT * 512);
+            const f4 sel0 = cem_ld_tab(et_rs, tv, CEM_ET_SEL0 * 512), sel1 = cem_ld_tab(et_rs, tv, CEM_ET_SEL1 * 512);
             f4 act4[RC], eps4[RC];
 #pragma unroll
             for (int c = 0; c < RC; ++c) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int af = f0 + r - O; af = af < 0 ? 0 : (af >= A ? A - 1 : af);
-                    act4[c][r] = actrow[c][tn * A + af];
-                }
+                CEM_LOAD_ACT(act4[c], i, c, tn);
                 if (MODE == 1 && p.eps_model) {
-                    const int tc = t < 0 ? 0 : t;
+                    const int f0 = 16 * Fo + 4 * q;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int fc = (f0 + r < O) ? f0 + r : O - 1;
-                        eps4[c][r] = p.eps_model[((size_t)tc * p.Btot + td.noise_row_base + slotc[c]) * O + fc];
+                        eps4[c][r] = p.eps_model[((size_t)t * p.Btot + td.noise_row_base + slotc[c]) * O + fc];
                     }
+                    eps4[c] = eps4[c] * (p.sampling ? 1.0f : 0.0f);
                 } else {
                     eps4[c] = cem_normal4((uint32_t)(td.noise_row_base + slotc[c]), (uint32_t)t, (uint32_t)p.it,
-                                          (uint32_t)(4 * Fo + q), CEM_STREAM_MODEL, key);
+                                          (uint32_t)(4 * Fo + q), CEM_STREAM_MODEL, key, rscale);
                 }
-                eps4[c] = eps4[c] * sampling;
             }
             f4 accm[RC], accv[RC];
 #pragma unroll
             for (int c = 0; c < RC; ++c) { accm[c] = bm; accv[c] = bv; }
             CEM_STAMP(2);
-            if (t >= 0) {
-                // the first heads stage also performs the exchange of the last hidden layer's output
-                if (Fo < p.KB_obs) {                                                           // wave-uniform
-                    if (i == 0) cem_mfma_stage<RC, CEM_NG, 2, false, CEM_X_EXCHANGE>(accm, accv, hB, wq, smem, xw ^ XB, lane, w);
-                    else cem_mfma_stage<RC, CEM_NG, 2, false, CEM_X_REREAD>(accm, accv, hB, wq, smem, xw ^ XB, lane, w);
-                } else if (i == 0) {
-                    __syncthreads();                      // keep the barrier count of waves without observation features
-                }
+            // the first heads stage also performs the exchange of the last hidden layer's output
+            if (Fo < p.KB_obs) {                                                           // wave-uniform
+                if (i == 0) cem_mfma_stage<RC, CEM_NG, 2, false, CEM_X_EXCHANGE>(accm, accv, hB, wq, smem, xw ^ XB, lane, w);
+                else cem_mfma_stage<RC, CEM_NG, 2, false, CEM_X_REREAD>(accm, accv, hB, wq, smem, xw ^ XB, lane, w);
+            } else if (i == 0) {
+                __syncthreads();                      // keep the barrier count of waves without observation features
             }
             CEM_STAMP(3);
 
 #pragma unroll
             for (int c = 0; c < RC; ++c) {
-                f4 sn = s[i][c], x;
+                const f4 mu = accm[c];
+                const f4 var = cem_softplus4(accv[c]) + 1e-4f;
+                f4 sd;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float mu = accm[c][r];
-                    const float sd = __builtin_amdgcn_sqrtf(cem_softplus(accv[c][r]) + 1e-4f);
-                    const float d = mu + sd * eps4[c][r];                         // Normal.sample = loc + scale*eps
-                    sn[r] = sn[r] + d * om4[r];                                    // s_t += d_s_t on observation features
-                    if (MODE == 1) {
-                        const int slot = 16 * c + j;
-                        if (t >= 0 && slot < td.cnt && f0 + r < O) {
-                            const size_t o = ((size_t)(td.row_base + slot) * H + t) * O + f0 + r;
-                            if (p.mu_out) p.mu_out[o] = mu;
-                            if (p.sd_out) p.sd_out[o] = sd;
-                        }
-                    }
-                    // closest_distance term of this feature, folded into the kinds it belongs to
-                    const float lid = fminf(fmaxf(p.sc.D - p.sc.D * (1.0f - sn[r]), 0.f), p.sc.D);
-                    const float gv = goalm != 0.f ? fmaxf(sn[r], 0.f) : lid;
-                    pm[0][c] = fminf(pm[0][c], fmaxf(gv, sel0[r]));
-                    pm[1][c] = fminf(pm[1][c], fmaxf(lid, sel1[r]));
-                    // next scaled input x = (concat[s, a] - min) * (1/delta); padding features have min 0, 1/delta 1, value 0
-                    const float xv = __builtin_fmaf(isact4[r], act4[c][r], sn[r]);   // s is 0 off the observation features
-                    x[r] = (xv - mn4[r]) * rd4[r];
-                }
-                s[i][c] = sn;
+                for (int r = 0; r < 4; ++r) sd[r] = __builtin_amdgcn_sqrtf(var[r]);
+                const f4 d = mu + sd * eps4[c];                                  // Normal.sample = loc + scale*eps
+                const f4 sn = s[i][c] + d * om4;                                 // s_t += d_s_t on observation features
                 if (MODE == 1) {
-                    const int slot = 16 * c + j;
-                    if (p.traj && slot < td.cnt) {
+                    const int slot = 16 * c + j, f0 = 16 * Fo + 4 * q;
+                    if (slot < td.cnt) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (f0 + r < O) p.traj[((size_t)(td.row_base + slot) * (H + 1) + (t + 1)) * O + f0 + r] = sn[r];
+                            if (f0 + r < O) {
+                                const size_t o = ((size_t)(td.row_base + slot) * H + t) * O + f0 + r;
+                                if (p.mu_out) p.mu_out[o] = mu[r];
+                                if (p.sd_out) p.sd_out[o] = sd[r];
+                                if (p.traj) p.traj[((size_t)(td.row_base + slot) * (H + 1) + (t + 1)) * O + f0 + r] = sn[r];
+                            }
                     }
                 }
+                s[i][c] = sn;
+                // closest_distance terms of these features, folded into the kinds they belong to
+                cem_scorer_terms(sn, p.sc.D, sel0, sel1, pm[0][c], pm[1][c]);
+                // next scaled input x = (concat[s, a] - min) * (1/delta); padding features have min 0, 1/delta 1, value 0
+                const f4 x = cem_sub4(__builtin_elementwise_fma(isact4, act4[c], sn), mn4) * rd4;   // s is 0 off the observation features
                 *reinterpret_cast<f4 *>(smem + xw + ((c * CEM_NG + Fo) * 64 + lane) * 16) = x;
                 xown[i][c] = x;
             }
@@ -578,39 +719,7 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
         for (int i = 0; i < NFW; ++i)
 #pragma unroll
             for (int c = 0; c < RC; ++c) hB[i][c] = xown[i][c];
-        // cost kinds beyond the first (vases+hazards+pillars+gremlins all constrained): rare, kept out of the main block
-        if (nk > 2) {
-#pragma unroll
-            for (int i = 0; i < NFW; ++i) {
-                const int f0 = 16 * (w + 4 * i) + 4 * q;
-                for (int k = 2; k < nk; ++k) {
-                    const f4 selk = *reinterpret_cast<const f4 *>(p.kind_sel + k * CEM_U + f0);
-#pragma unroll
-                    for (int c = 0; c < RC; ++c)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float lid = fminf(fmaxf(p.sc.D - p.sc.D * (1.0f - s[i][c][r]), 0.f), p.sc.D);
-                            const float v = fminf(pm[k][c], fmaxf(lid, selk[r]));
-                            pm[k][c] = v;
-                        }
-                }
-            }
-        }
-        // min over the 4 lane rows holding different features of the same batch row: two VALU row swaps (no LDS)
-#pragma unroll
-        for (int k = 0; k < CEM_NKIND; ++k) {
-            if (k < 2 || k < nk) {
-#pragma unroll
-                for (int c = 0; c < RC; ++c) {
-                    const uint32_t mb = __float_as_uint(pm[k][c]);
-                    const auto r16 = __builtin_amdgcn_permlane16_swap(mb, mb, false, false);
-                    const float m16 = fminf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
-                    const uint32_t m16b = __float_as_uint(m16);
-                    const auto r32 = __builtin_amdgcn_permlane32_swap(m16b, m16b, false, false);
-                    part[(k * 4 + w) * 64 + 16 * c + j] = fminf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));   // all 4 rows store the same value
-                }
-            }
-        }
+        CEM_RARE_KINDS_AND_STORE();
         xw ^= XB;
         CEM_STAMP(4);
     }
@@ -618,7 +727,7 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
     __syncthreads();
     CEM_BOOKKEEP(t_end - 1);
     if (!SEG || t_end == H) {
-        if (w == 0 && lane < td.cnt) p.ret[td.row_base + lane] = cum;
+        if (w == wbk && lane < td.cnt) p.ret[td.row_base + lane] = cum;
     } else {
 #pragma unroll
         for (int i = 0; i < NFW; ++i)
@@ -627,13 +736,17 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
                 cem_st_coherent(seg_rs, ((i * RC + c) * 256 + tid) * 16, s[i][c]);
                 cem_st_coherent(seg_rs, (((NFW + i) * RC + c) * 256 + tid) * 16, hB[i][c]);
             }
-        if (w == 0) cem_st_coherent(seg_rs, (2 * NFW * RC * 256 + lane) * 16, (f4){d_prev, c_prev, cum, done ? 1.0f : 0.0f});
+        if (w == wbk) cem_st_coherent(seg_rs, (2 * NFW * RC * 256 + lane) * 16, (f4){d_prev, c_prev, cum, done ? 1.0f : 0.0f});
     }
 #ifdef CEM_STAMPS
     if (p.stamps && lane == 0) for (int i = 0; i < 8; ++i) p.stamps[((size_t)tile_idx * 4 + w) * 8 + i] = st_[i];
 #endif
 }
 #undef CEM_BOOKKEEP
+#undef CEM_PART_MIN4
+#undef CEM_PAIR_MIN_STORE
+#undef CEM_RARE_KINDS_AND_STORE
+#undef CEM_LOAD_ACT
 
 template <int RC, int NFW, int MODE>
 __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
@@ -719,6 +832,7 @@ __global__ void cem_init_kernel(const InitParams p)
 
 struct SampleParams {
     float *actions; const float *musig; const float *eps_act; const CtrlBlock *ctrl;
+    float *act_pad; int32_t pad_shift, pad_floats;          // RolloutParams::act_pad as floats: action a of (n, t) at [(n*H + t)*pad_floats + pad_shift + a]
     int32_t N, H, A, it, check_done;
     float lb[32], ub[32];
     uint32_t *seg_queue, *seg_flags; int32_t n_ready;      // work queue of this iteration's rollout launch, reset here (or null)
@@ -746,6 +860,7 @@ __global__ __launch_bounds__(256) void cem_sample_kernel(const SampleParams p)
                 float v = eps * p.musig[HA + t * p.A + a] + p.musig[t * p.A + a];          // tf.random.normal(mean, stddev)
                 v = fminf(fmaxf(v, p.lb[a]), p.ub[a]);                                      // tf.clip_by_value
                 p.actions[((size_t)n * p.H + t) * p.A + a] = v;
+                if (p.act_pad) p.act_pad[((size_t)n * p.H + t) * p.pad_floats + p.pad_shift + a] = v;   // padding words stay 0 (zeroed at create)
             }
         }
     }
@@ -1513,6 +1628,19 @@ __global__ void cem_final_kernel(const FinalParams p)
         reinterpret_cast<int32_t *>(p.result)[34] = p.ctrl->done;
         reinterpret_cast<int32_t *>(p.result)[35] = p.ctrl->fault;
     }
+}
+
+// the raw Philox4x32-7 words of n counters (idx0 + i, t | it << 16, sub | stream << 16, call_lo) — what cem_normal4 turns into four
+// normals — so that a test can hold the generator against an independent implementation word for word (cem_philox_words)
+struct WordsParams { uint32_t *out; const CtrlBlock *ctrl; uint32_t stream, it, t, sub, idx0, n; };
+__global__ __launch_bounds__(256) void cem_philox_words_kernel(const WordsParams p)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    const PhiloxKey key = cem_key(p.ctrl);
+    uint32_t c0 = p.idx0 + i, c1 = p.t | (p.it << 16), c2 = p.sub | (p.stream << 16), c3 = key.c3;
+    philox4x32_7(c0, c1, c2, c3, key.k0, key.k1);
+    p.out[4 * (size_t)i + 0] = c0; p.out[4 * (size_t)i + 1] = c1; p.out[4 * (size_t)i + 2] = c2; p.out[4 * (size_t)i + 3] = c3;
 }
 
 struct FillParams { float *eps_act, *eps_model, *eps_out; const CtrlBlock *ctrl; int32_t I, N, H, A, B, O; };

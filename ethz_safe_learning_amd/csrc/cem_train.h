@@ -549,8 +549,7 @@ __global__ __launch_bounds__(256) void cem_adam_kernel(const TrainParams p)
         upd(g, p.Mo[e], p.Vo[e], p.W[e]);
     }
     // training_step's return value, per member: negative_log_likelihood / ensemble_size (mlp_ensemble.py:64-67,139-141)
-    if (blockIdx.x == 0 && (int)threadIdx.x < p.E) {
-        const int m = threadIdx.x;
+    if (blockIdx.x == 0) for (int m = threadIdx.x; m < p.E; m += blockDim.x) {       // any ensemble size (the reference takes any)
         float s_log = 0.f, s_sq = 0.f;
         for (int q = 0; q < nparts; ++q) { s_log = s_log + p.loss_part[((size_t)m * CEM_TPARTS + q) * 2]; s_sq = s_sq + p.loss_part[((size_t)m * CEM_TPARTS + q) * 2 + 1]; }
         const float cnt = (float)p.Bt * (float)p.O;

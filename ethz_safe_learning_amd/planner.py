@@ -409,6 +409,13 @@ class CemPlanner:
         _capi.check(self.lib.cem_fill_noise(self.h, seed, call, _ptr(ea), _ptr(em), _ptr(eo)), 'cem_fill_noise')
         return ea, em, eo
 
+    def philox_words(self, seed, call, stream, iteration, t, sub, idx0, n):
+        """The generator's raw Philox4x32-7 output words for n consecutive counters (test hook, cem_mpc.h): uint32 [n, 4]."""
+        out = self._torch.empty((n, 4), dtype=self._torch.int32, device=self.device)
+        self._wait_inputs()
+        _capi.check(self.lib.cem_philox_words(self.h, seed, call, stream, iteration, t, sub, idx0, n, _ptr(out)), 'cem_philox_words')
+        return out.cpu().numpy().view('uint32')
+
     def set_timing(self, enable=True):
         _capi.check(self.lib.cem_planner_set_timing(self.h, int(enable)), 'cem_planner_set_timing')
 

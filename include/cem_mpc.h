@@ -216,6 +216,15 @@ int cem_scorer_cost(cem_planner_t *h, const float *obs_dev, int32_t n, float *co
 /* dump the Philox streams a (seed, call) plan consumes, in the explicit-tensor layouts above (device pointers; any may be NULL) */
 int cem_fill_noise(cem_planner_t *h, uint64_t seed, uint64_t call, float *eps_act_dev, float *eps_model_dev, float *eps_out_dev);
 
+/* The generator behind those streams, word for word (test hook): the four Philox4x32-7 output words of the n counters
+ *   (idx0 + i,  t | iteration << 16,  sub | stream << 16,  call & 0xffffffff),  key (seed & 0xffffffff, (seed >> 32) ^ (call >> 32)),
+ * written to words_out_dev[n][4] (uint32).  stream: 0 model noise (idx = global batch row, sub = feature quad), 1 action noise
+ * (idx = candidate, sub = action quad), 2 output noise (idx = action quad, t = iteration = sub = 0).  Four normals of a counter:
+ *   u_k = fl32(fl32(word_k) * 2^-32 + 2^-33);  z0 = r(u0) cos(2 pi u1), z1 = r(u0) sin(2 pi u1), z2 = r(u2) cos(2 pi u3),
+ *   z3 = r(u2) sin(2 pi u3),  r(u) = sqrt(-2 ln u)   (tf.random.normal draws of cem_mpc.py:44-47,68 and mlp_ensemble.py:192-193) */
+int cem_philox_words(cem_planner_t *h, uint64_t seed, uint64_t call, uint32_t stream, uint32_t iteration, uint32_t t, uint32_t sub,
+                     uint32_t idx0, uint32_t n, uint32_t *words_out_dev);
+
 /* device time (ms) of the rollout kernels of the last plan, measured with HIP events on the handle's stream
  * (enabled by cem_planner_set_timing(h, 1); costs one event pair per launch). */
 int cem_planner_set_timing(cem_planner_t *h, int32_t enable);
