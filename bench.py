@@ -27,6 +27,27 @@ PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 SHADER_CLOCK_HZ = 2.4e9            # MI355X peak engine clock (MI355X_MICROARCH.md)
 
 
+def source_sha16():
+    """Identity of the device code a profile was collected on: sha256 over the kernel sources and the C ABI header.  The PMC
+    summaries under profiles/ carry it (scripts/summarise_profiles.py); a bench run only quotes counters whose hash matches."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'ethz_safe_learning_amd', 'csrc', '*.h')) + glob.glob(os.path.join(ROOT, 'ethz_safe_learning_amd', 'csrc', '*.hip')) +
+                    glob.glob(os.path.join(ROOT, 'include', '*.h'))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def rollout_kernel_name(pl, obs, act):
+    """The instantiation this plan launches, as rocprofv3 prints it (cem_capi.hip: launch_rollout / launch_rollout_seg)."""
+    rc = pl.tiles()[0]
+    nfw = ((obs + act + 15) // 16 + 3) // 4
+    if pl.segments()[0] > 1:
+        return 'void cem_rollout_seg_kernel<%d, %d>(RolloutParams)' % (rc, nfw)
+    return 'void cem_rollout_kernel<%d, %d, 0>(RolloutParams)' % (rc, nfw)
+
+
 def cpu_baseline(budget_s=25.0):
     """The repo's own CPU path as SURVEY.md 8d defines it: the oracle in its fast form (oracle/cem_oracle_fast.py, a port:
     torch-CPU fp32, one batched matmul over members per layer), timed on this box's host cores on a bounded sample of the
@@ -88,6 +109,90 @@ def cpu_baseline(budget_s=25.0):
                 b1=res['B1'], b2=res['B2'])
 
 
+def b5_leg(torch, dist, pb, G, rank, dev, native, steps, warmup, rehearse_world=0):
+    """BASELINE.json configs[4], strong-scaled: N = 65536 candidates (K = P = E = 5, H = 30, I = 5, k = 6554) sharded over the G
+    ranks of this run, one all-gather of the scores per CEM iteration.  Timed like the headline: barrier + synchronize on both
+    sides, max over ranks.  `rehearse_world` = R > 0 (CEM_BENCH_B5_REHEARSAL=R on a one-GPU box): this process plays rank 0 of R —
+    65536/R candidates, the replicated sample and select over all 65536 — with the all-gather replaced by a device copy of its
+    own shard (the other ranks' scores keep plausible stale values), as scripts/time_b5_rank.py does; the stepwise C-ABI calls are
+    the ones the host-stepped multi-rank driver makes."""
+    from ethz_safe_learning_amd import CemPlanner, PlannerConfig, synthetic
+    obs, act, K, H, I, N, k = 60, 2, 5, 30, 5, 65536, 6554
+    W = rehearse_world or G
+    cfg = PlannerConfig(obs_dim=obs, act_dim=act, ensemble_size=K, particles=K, n_samples=N, horizon=H, n_elite=k, iterations=I,
+                        scorer=pb['scorer'], act_low=pb['low'], act_high=pb['high'], stddev_threshold=-1.0, noise_stddev=1e-3, variant='cem',
+                        world_size=W, rank=0 if rehearse_world else rank, use_graph=not rehearse_world)
+    pl = CemPlanner(cfg, device=dev)
+    pl.set_weights(pb['weights'])
+    pl.set_normaliser(pb['inputs_min'], pb['inputs_max'])
+    n_seen = 0
+    if rehearse_world:
+        exchange = 'rehearsal: device copy of this rank\'s shard (1 process playing rank 0 of %d)' % W
+        pl.scores_global().copy_(torch.from_numpy(np.random.default_rng(0).standard_normal(N).astype(np.float32)))
+        lo, hi = 0, N // W
+
+        def one_plan(i):
+            pl.plan_begin(pb['state'], seed=2028, call=i)
+            for it in range(I):
+                pl.plan_rollout(it)
+                with torch.cuda.stream(pl.stream):
+                    pl.scores_global()[lo:hi].copy_(pl.scores_local())
+                pl.plan_select(it)
+            return pl.plan_end()
+    elif native:
+        pl.comm_init()
+        n_seen = pl.comm_ranks()
+        assert n_seen == G, 'rank %d: the RCCL communicator has %d ranks, --gpus is %d' % (rank, n_seen, G)
+        exchange = 'ncclAllGather inside the library, on the planner stream'
+
+        def one_plan(i):
+            return pl.plan(pb['state'], seed=2028, call=i)
+    else:
+        from ethz_safe_learning_amd.sharded import ShardedCemDriver
+        drv = ShardedCemDriver(pl, I, world_size=G, always_exchange=True)
+        exchange = 'torch.distributed all_gather between ctypes calls'
+
+        def one_plan(i):
+            return drv.plan(pb['state'], seed=2028, call=i)
+    for i in range(warmup):
+        one_plan(i)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        a, s, it = one_plan(warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert it == I and np.all(np.isfinite(a))
+    pl.set_timing(True)
+    roll_ms, sel_ms, roll_n = 0.0, 0.0, 0
+    for i in range(3):
+        one_plan(1000 + i)
+        tm = pl.last_timing()
+        roll_ms += tm['rollout_ms']; sel_ms += tm['select_ms']; roll_n += tm['rollout_launches']
+    pl.set_timing(False)
+    flops_launch = synthetic.flops_per_row_step(obs, act) * K * (N // W) * H
+    avg_ms = roll_ms / max(roll_n, 1)
+    out = dict(workload='B5: obs=60 act=2 K=P=E=5 N=65536 H=30 I=5 k=6554, strong-scaled over %d ranks' % W, scaling='strong',
+               plans_per_s=steps / dt, ms_per_plan=1e3 * dt / steps, steps=steps, n_ranks=W, candidates_per_rank=N // W,
+               candidate_trajectory_steps_per_s=steps / dt * I * N * H,
+               rollout_ms_per_launch=avg_ms, rollout_frac_of_fp32_mfma_peak_per_rank=flops_launch / (avg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+               rollout_kernel=rollout_kernel_name(pl, obs, act), select_us_per_iteration=1e3 * sel_ms / max(roll_n, 1),
+               chunks_per_tile=pl.tiles()[0], tiles=int(len(pl.tiles()[1])), exchange=exchange, n_ranks_seen_by_rccl=n_seen,
+               hip_graph=pl.graph_status() == 'graph')
+    if native and not rehearse_world:
+        pl.comm_destroy()
+    pl.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -141,6 +246,7 @@ def main():
         # to the host-stepped exchange (torch.distributed all_gather between the library calls) on all ranks if it did not
         try:
             pl.comm_init()
+            assert pl.comm_ranks() == G, 'the RCCL communicator has %d ranks, --gpus is %d' % (pl.comm_ranks(), G)
             ok = 1
         except Exception as e:                        # e.g. librccl not loadable from the library, ncclCommInitRank refused
             sys.stderr.write('rank %d: native RCCL exchange unavailable (%s); using the host-stepped exchange\n' % (rank, e))
@@ -194,14 +300,25 @@ def main():
     avg_ms = roll_ms / max(roll_n, 1)
     achieved = flops_launch / (avg_ms * 1e-3) / 1e12
 
-    mfma_util = None
-    traffic = None                 # HBM-side bytes per rollout launch from the committed rocprofv3 TCC passes (same workload)
+    # HBM-side bytes and MFMA-pipe busy cycles per rollout launch come from the committed rocprofv3 PMC passes of this same
+    # workload (counters cannot be collected inside a timed run).  They are only quoted when that profile is of THIS code and THIS
+    # kernel: the summary records the kernel name and a hash of the device sources; anything else is reported as stale, not reused.
+    kname = rollout_kernel_name(pl, obs, act)
+    mfma_util, traffic, profile_note = None, None, None
     tpath = os.path.join(ROOT, 'profiles', 'traffic_b2.json')
-    if G == 1 and args.n_per_gpu == 2000 and os.path.exists(tpath):
-        prof = json.load(open(tpath))
-        traffic = prof['hbm_bytes_per_launch']
-        # MFMA-pipe utilisation: PMC busy cycles per launch (committed rocprofv3 pass) over 1024 SIMDs x this run's launch time
-        mfma_util = prof.get('sq_valu_mfma_busy_cycles_per_launch', 0.0) / (1024 * avg_ms * 1e-3 * SHADER_CLOCK_HZ) or None
+    if G == 1 and args.n_per_gpu == 2000:
+        if not os.path.exists(tpath):
+            profile_note = 'no PMC profile committed'
+        else:
+            prof = json.load(open(tpath))
+            if prof.get('kernel') != kname:
+                profile_note = 'stale_profile: profiles/traffic_b2.json is of kernel %r, this run launched %r' % (prof.get('kernel'), kname)
+            elif prof.get('source_sha16') != source_sha16():
+                profile_note = 'stale_profile: profiles/traffic_b2.json was collected on device sources %s, this run is %s' % (prof.get('source_sha16'), source_sha16())
+            else:
+                traffic = prof['hbm_bytes_per_launch']
+                # MFMA-pipe utilisation: PMC busy cycles per launch over 1024 SIMDs x this run's launch time
+                mfma_util = prof.get('sq_valu_mfma_busy_cycles_per_launch', 0.0) / (1024 * avg_ms * 1e-3 * SHADER_CLOCK_HZ) or None
 
     plans_per_s = args.steps / dt
     b2_equiv = plans_per_s * (N / 2000.0)
@@ -223,9 +340,17 @@ def main():
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'mfma_busy_frac': mfma_util,
                      'hbm_gbps': (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None, 'hbm_peak_gbps': PEAK_HBM_GBPS,
-                     'kernel': 'cem_rollout_seg_kernel<1, 1>' if pl.segments()[0] > 1 else 'cem_rollout_kernel<%d, 1, 0>' % pl.tiles()[0], 'avg_launch_ms': avg_ms, 'launches_timed': roll_n,
+                     'kernel': kname, 'profile_note': profile_note, 'avg_launch_ms': avg_ms, 'launches_timed': roll_n,
                      'algorithmic_flops_per_launch': flops_launch},
     }
+    # BASELINE config 5 (N = 65536 over the node's GPUs) rides along on every multi-GPU run; CEM_BENCH_B5_REHEARSAL=R rehearses one
+    # rank of R on a one-GPU box
+    rehearse = int(os.environ.get('CEM_BENCH_B5_REHEARSAL', '0'))
+    if G > 1 or rehearse > 0:
+        if native:
+            pl.comm_destroy()                          # one communicator at a time
+        out['b5'] = b5_leg(torch, dist, pb, G, rank, dev, native, steps=min(args.steps, 20), warmup=min(max(args.warmup, 2), 5),
+                           rehearse_world=rehearse if G == 1 else 0)
     if rank == 0 and G == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     if rank == 0:

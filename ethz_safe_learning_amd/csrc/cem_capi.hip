@@ -222,33 +222,34 @@ void build_plan_tiles(const Dims &d, int rc, std::vector<Tile6> &out)
 // ---- tile-size choice ------------------------------------------------------------------------------------------------
 // A tile is 16*rc rows of one member; a CU keeps as many workgroups resident as their registers allow.  fp32 MFMA and
 // VALU work add up on a SIMD whichever wave they come from, so a co-resident workgroup cannot hide arithmetic — but it
-// does hide the stalls (barrier skew, LDS and L2 latency at the stage boundaries), and that is worth 8-20 % per chunk.
-// Cost of one 16-row chunk for the whole horizon, in units of the measured B-config sweeps (ms at H = 30, MI355X, round 1:
-// profiles/r01_sweep_chunks.txt): `solo` with one workgroup on the CU, `shared` with two or more.  Larger tiles re-use each
-// streamed weight group for more rows (less L2 traffic); smaller tiles pack the CUs more evenly and co-reside more easily.
-static const double kChunkSolo[2][4] = {{0.192, 0.168, 0.159, 0.157}, {1.25, 1.056, 1.010, 0.999}};
-static const double kChunkShared[2][4] = {{0.153, 0.148, 0.1445, 0.1445}, {1.00, 0.949, 0.93, 0.92}};
+// does hide the stalls (barrier skew, LDS and L2 latency at the stage boundaries).  Cost of one 16-row chunk for the whole
+// horizon in ms at H = 30 on MI355X, measured with exactly m tiles per CU (scripts/sweep_chunk_costs.py, round 3:
+// profiles/r03_chunk_costs.jsonl): kChunkStart[nfw][rc][k-1] when k tiles start together on a CU and all stay resident (k up to
+// the residency), kChunkNext[nfw][rc] for every further tile the dispatcher starts as an earlier one retires (fitted to the
+// BASELINE-config sweeps at forced tile sizes, profiles/r03_sweep_forced_chunks.txt: B3 32 and B5 10 chunks per CU, B4 8).
+// Larger tiles re-use each streamed weight group for more rows; smaller ones pack the CUs more evenly and co-reside more easily.
+static const double kChunkStart[2][4][3] = {{{0.2003, 0.1728, 0.1649}, {0.1596, 0.1443, 0.1383}, {0.1493, 0.1376, 0.1376}, {0.1456, 0.1364, 0.1364}},
+                                            {{0.2480, 0.2103, 0.1970}, {0.2122, 0.1908, 0.1908}, {0.1999, 0.1856, 0.1856}, {0.1959, 0.1959, 0.1959}}};
+static const double kChunkNext[2][4] = {{0.1350, 0.1330, 0.1335, 0.1330}, {0.1874, 0.1845, 0.1807, 0.1932}};
 #define CEM_MAX_DEVICES 64
-// workgroups of a <rc, nfw> tile one CU keeps resident, from the kernels' VGPR counts (plain / segment kernel, round 3: 139/159/186/218,
-// 165/217/253/288 and 144/163/190/223, 171/221/255/292; 512 registers per SIMD lane): the smaller of the two forms' answers
-static const int kResidentStatic[2][4] = {{3, 3, 2, 2}, {2, 2, 2, 1}};
+// workgroups of a <rc, nfw> tile one CU keeps resident, from the kernels' VGPR counts (512 registers per SIMD lane; round 3:
+// plain kernel 139/159/186/218, 165/217/253/288; segment kernel 144/163/190/223, 171/221/255/292), [form][nfw - 1][rc - 1]
+static const int kResidentStatic[2][2][4] = {{{3, 3, 2, 2}, {3, 2, 2, 1}}, {{3, 3, 2, 2}, {2, 2, 2, 1}}};
 
 template <int RC, int NFW>
-int query_resident()
+int query_resident(bool seg)
 {
-    int n = 0, ns = 0;
+    int n = 0;
     const size_t lds = (size_t)2 * RC * CEM_NG * 1024 + CEM_PART_FLOATS * 4;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cem_rollout_kernel<RC, NFW, 0>, 256, lds) != hipSuccess || n < 1 ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&ns, cem_rollout_seg_kernel<RC, NFW>, 256, lds) != hipSuccess || ns < 1) {
-        (void)hipGetLastError();
-        return 0;
-    }
-    return std::min(n, ns);
+    const hipError_t e = seg ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cem_rollout_seg_kernel<RC, NFW>, 256, lds)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cem_rollout_kernel<RC, NFW, 0>, 256, lds);
+    if (e != hipSuccess || n < 1) { (void)hipGetLastError(); return 0; }
+    return n;
 }
 
 // Per-device facts the tile plan is priced with, asked from the runtime once per device (thread-safe: one std::call_once per
 // device slot; the last slot serves a process without a device and holds the static tables).
-struct DeviceFacts { std::once_flag once; int resident[2][4]; int cus; };
+struct DeviceFacts { std::once_flag once; int resident[2][2][4]; int cus; };
 static DeviceFacts g_facts[CEM_MAX_DEVICES + 1];
 
 const DeviceFacts &device_facts()
@@ -259,17 +260,18 @@ const DeviceFacts &device_facts()
     DeviceFacts &f = g_facts[dev];
     std::call_once(f.once, [&] {
         const bool have = dev < CEM_MAX_DEVICES;
-        for (int nfw = 1; nfw <= 2; ++nfw)
-            for (int rc = 1; rc <= 4; ++rc) {
-                int n = 0;
-                if (have) {
-#define CEM_CASE(R, F) if (rc == R && nfw == F) n = query_resident<R, F>();
-                    CEM_CASE(1, 1) CEM_CASE(2, 1) CEM_CASE(3, 1) CEM_CASE(4, 1)
-                    CEM_CASE(1, 2) CEM_CASE(2, 2) CEM_CASE(3, 2) CEM_CASE(4, 2)
+        for (int seg = 0; seg < 2; ++seg)
+            for (int nfw = 1; nfw <= 2; ++nfw)
+                for (int rc = 1; rc <= 4; ++rc) {
+                    int n = 0;
+                    if (have) {
+#define CEM_CASE(R, F) if (rc == R && nfw == F) n = query_resident<R, F>(seg != 0);
+                        CEM_CASE(1, 1) CEM_CASE(2, 1) CEM_CASE(3, 1) CEM_CASE(4, 1)
+                        CEM_CASE(1, 2) CEM_CASE(2, 2) CEM_CASE(3, 2) CEM_CASE(4, 2)
 #undef CEM_CASE
+                    }
+                    f.resident[seg][nfw - 1][rc - 1] = n > 0 ? n : kResidentStatic[seg][nfw - 1][rc - 1];
                 }
-                f.resident[nfw - 1][rc - 1] = n > 0 ? n : kResidentStatic[nfw - 1][rc - 1];
-            }
         f.cus = 256;                                // MI355X; a partitioned or different device reports its own count
         hipDeviceProp_t pr;
         if (have && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) f.cus = pr.multiProcessorCount;
@@ -278,7 +280,8 @@ const DeviceFacts &device_facts()
     return f;
 }
 
-int resident_workgroups(int nfw, int rc) { return device_facts().resident[nfw - 1][rc - 1]; }
+// seg: the pinned + floating-segment launch (cem_rollout_seg_kernel) instead of one workgroup per tile (cem_rollout_kernel)
+int resident_workgroups(int nfw, int rc, bool seg = false) { return device_facts().resident[seg ? 1 : 0][nfw - 1][rc - 1]; }
 int num_cus() { return device_facts().cus; }
 
 // ---- pinned tiles + floating horizon segments ----------------------------------------------------------------------------
@@ -291,34 +294,41 @@ int num_cus() { return device_facts().cus; }
 // partner and a floater's 30-step chain plus its hand-overs is as long as two whole tiles) and none when the remainder nearly
 // fills the CUs anyway (750 tiles: 0.498 -> 0.492).  Hence: at least two pinned tiles per CU, and a predicted gain of > 4 %.
 static const int kSegMaxSegments = 6, kSegMinSteps = 5;
-static const double kFloatOverhead = 1.08;  // floating launch vs the mean-load ideal (B2: 0.405 ms vs 2.44 x 0.153 ms)
+static const double kFloatFactor = 0.96;    // pinned + floating launch vs (mean tiles per CU) x the all-resident chunk cost (B2, round 3: 0.3857 ms vs 2.44 x 0.1649)
+
+// cost of `per_cu` tiles of rc chunks queued on one CU that keeps `occ` resident
+double cu_cost(int nfw, int rc, long per_cu, int occ)
+{
+    const long k = std::min<long>(per_cu, std::min(occ, 3));
+    if (k < 1) return 0.0;
+    return (double)rc * ((double)k * kChunkStart[nfw - 1][rc - 1][k - 1] + (double)(per_cu - k) * kChunkNext[nfw - 1][rc - 1]);
+}
 
 int segments_for(const Dims &d, int rc, size_t n_tiles, int requested)
 {
     if (requested == 1 || n_tiles >= (size_t)1 << 23) return 1;       // items are packed as (tile << 8 | segment)
     auto clamp_to_horizon = [&](int S) { S = std::min(S, d.H); while (S > 1 && (d.H + S - 1) / S * (S - 1) >= d.H) --S; return std::max(S, 1); };
     if (requested > 1) return clamp_to_horizon(requested);
-    const int occ = resident_workgroups(d.NFW, rc), kNumCUs = num_cus();
+    const int occ = resident_workgroups(d.NFW, rc, true), kNumCUs = num_cus();
     if (n_tiles < (size_t)2 * kNumCUs || n_tiles > (size_t)kNumCUs * occ) return 1;  // < 2 pinned tiles per CU: no gain (measured);
                                                                                   // more tiles than slots: the dispatcher already refills
     const int S = clamp_to_horizon(std::min(kSegMaxSegments, d.H / kSegMinSteps));
     if (S < 2) return 1;
     const double L = (double)n_tiles / kNumCUs;
-    return std::ceil(L) / (kFloatOverhead * L) > 1.04 ? S : 1;
+    const long per_cu = (long)std::ceil(L);
+    const double plain = cu_cost(d.NFW, rc, per_cu, occ), floating = (double)rc * L * kChunkStart[d.NFW - 1][rc - 1][std::min<long>(per_cu, 3) - 1] * kFloatFactor;
+    return plain / floating > 1.04 ? S : 1;
 }
 
 double tile_plan_cost(const Dims &d, int rc, size_t n_tiles, int requested_segments)
 {
-    const int occ = resident_workgroups(d.NFW, rc), kNumCUs = num_cus();
+    const int kNumCUs = num_cus();
     const int S = segments_for(d, rc, n_tiles, requested_segments);
-    if (S > 1 && n_tiles > (size_t)kNumCUs) {     // pinned tiles + floating segments: every CU carries the mean load, plus hand-over costs
-        const bool alone = n_tiles / kNumCUs < 2;  // one pinned tile per CU: it runs without a partner most of the time
-        return (double)rc * (alone ? kChunkSolo : kChunkShared)[d.NFW - 1][rc - 1] * ((double)n_tiles / kNumCUs) * kFloatOverhead;
-    }
+    const double L = (double)n_tiles / kNumCUs;
     const long per_cu = (long)((n_tiles + kNumCUs - 1) / kNumCUs);
-    const long full = per_cu / occ, rem = per_cu % occ;
-    auto c = [&](long resident) { return resident >= 2 ? kChunkShared[d.NFW - 1][rc - 1] : kChunkSolo[d.NFW - 1][rc - 1]; };
-    return (double)rc * ((double)(full * occ) * c(occ) + (double)rem * c(rem));
+    if (S > 1 && n_tiles > (size_t)kNumCUs)       // pinned tiles + floating segments: every CU carries the mean load
+        return (double)rc * L * kChunkStart[d.NFW - 1][rc - 1][std::min<long>(per_cu, 3) - 1] * kFloatFactor;
+    return cu_cost(d.NFW, rc, per_cu, resident_workgroups(d.NFW, rc, false));
 }
 
 int auto_chunks(const Dims &d, int requested_segments)
@@ -413,6 +423,7 @@ struct Rccl {
     int (*CommInitRank)(void **, int, CemNcclId, int) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
 };
 Rccl *rccl()
 {
@@ -428,6 +439,7 @@ Rccl *rccl()
             r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
             r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
             r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+            r.CommCount = (decltype(r.CommCount))dlsym(r.lib, "ncclCommCount");     // optional: only cem_planner_comm_ranks needs it
             if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) r.lib = nullptr;
         }
     });
@@ -550,15 +562,18 @@ int cem_plan_segments_host(const cem_config_t *cfg, int32_t *segments_out, int32
 
 int cem_rollout_residency(int32_t chunks_per_tile, int32_t input_blocks_per_wave, int32_t *table_out, int32_t *runtime_out)
 {
+    // [0]: one workgroup per tile (cem_rollout_kernel), [1]: the pinned + floating-segment form (cem_rollout_seg_kernel)
     if (chunks_per_tile < 1 || chunks_per_tile > 4 || input_blocks_per_wave < 1 || input_blocks_per_wave > 2) return CEM_ERR_INVALID_ARG;
-    if (table_out) *table_out = kResidentStatic[input_blocks_per_wave - 1][chunks_per_tile - 1];
-    if (runtime_out) {
-        int n = 0;
-#define CEM_CASE(R, F) if (chunks_per_tile == R && input_blocks_per_wave == F) n = query_resident<R, F>();
-        CEM_CASE(1, 1) CEM_CASE(2, 1) CEM_CASE(3, 1) CEM_CASE(4, 1)
-        CEM_CASE(1, 2) CEM_CASE(2, 2) CEM_CASE(3, 2) CEM_CASE(4, 2)
+    for (int seg = 0; seg < 2; ++seg) {
+        if (table_out) table_out[seg] = kResidentStatic[seg][input_blocks_per_wave - 1][chunks_per_tile - 1];
+        if (runtime_out) {
+            int n = 0;
+#define CEM_CASE(R, F) if (chunks_per_tile == R && input_blocks_per_wave == F) n = query_resident<R, F>(seg != 0);
+            CEM_CASE(1, 1) CEM_CASE(2, 1) CEM_CASE(3, 1) CEM_CASE(4, 1)
+            CEM_CASE(1, 2) CEM_CASE(2, 2) CEM_CASE(3, 2) CEM_CASE(4, 2)
 #undef CEM_CASE
-        *runtime_out = n;
+            runtime_out[seg] = n;
+        }
     }
     return CEM_OK;
 }
@@ -1093,6 +1108,18 @@ int cem_planner_comm_init(cem_planner_t *h, const void *id, int32_t n_ranks, int
     if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
     if (h->graph) { hipGraphDestroy(h->graph); h->graph = nullptr; }
     h->graph_ready = false; h->graph_failed = false;
+    return CEM_OK;
+}
+
+int cem_planner_comm_ranks(const cem_planner_t *h, int32_t *n_ranks_out)
+{
+    if (!h || !n_ranks_out) return CEM_ERR_INVALID_ARG;
+    *n_ranks_out = 0;
+    if (!h->comm) return CEM_OK;                     // no communicator: 0
+    Rccl *r = rccl(); if (!r || !r->CommCount) return CEM_ERR_COMM;
+    int n = 0;
+    NCCLCHK(r->CommCount(h->comm, &n));
+    *n_ranks_out = n;
     return CEM_OK;
 }
 

@@ -260,6 +260,12 @@ class CemPlanner:
             _capi.check(self.lib.cem_planner_comm_init(self.h, buf, c.world_size, c.rank), 'cem_planner_comm_init')
         self.has_comm = True
 
+    def comm_ranks(self):
+        """Ranks of the handle's RCCL communicator as RCCL reports them (0 without one)."""
+        n = C.c_int32()
+        _capi.check(self.lib.cem_planner_comm_ranks(self.h, C.byref(n)), 'cem_planner_comm_ranks')
+        return n.value
+
     def comm_destroy(self):
         _capi.check(self.lib.cem_planner_comm_destroy(self.h), 'cem_planner_comm_destroy')
         self.has_comm = False

@@ -146,8 +146,9 @@ int cem_plan_tiles_host(const cem_config_t *cfg, int32_t *chunks_per_tile_out, i
 /* horizon segments the rollout launch of this configuration uses (1 = unsegmented), as cem_planner_create would choose */
 int cem_plan_segments_host(const cem_config_t *cfg, int32_t *segments_out, int32_t *steps_per_segment_out);
 
-/* diagnostic: workgroups of the rollout kernel for (chunks_per_tile, obs+act <= 64 ? 1 : 2 input blocks per wave) one CU keeps
- * resident — what the tile-size choice assumes (`table_out`) and what the HIP runtime reports (`runtime_out`, 0 without a device). */
+/* diagnostic: workgroups of the rollout kernels for (chunks_per_tile, obs+act <= 64 ? 1 : 2 input blocks per wave) one CU keeps
+ * resident — what the tile-size choice assumes (`table_out[2]`) and what the HIP runtime reports (`runtime_out[2]`, 0 without a
+ * device); element 0: one workgroup per tile, element 1: the pinned + floating-segment launch form. */
 int cem_rollout_residency(int32_t chunks_per_tile, int32_t input_blocks_per_wave, int32_t *table_out, int32_t *runtime_out);
 
 /* lifecycle.  `workspace` is device memory of >= cem_workspace_bytes(cfg), 256-B aligned; `hip_stream` a hipStream_t (NULL = default). */
@@ -187,6 +188,8 @@ int cem_plan_end(cem_planner_t *h, const float *eps_out_host, float *action_out,
 int cem_comm_unique_id(void *id_out /* CEM_COMM_ID_BYTES */);
 int cem_planner_comm_init(cem_planner_t *h, const void *id /* CEM_COMM_ID_BYTES */, int32_t n_ranks, int32_t rank);
 int cem_planner_comm_destroy(cem_planner_t *h);
+/* ranks of the handle's communicator as RCCL itself reports them (ncclCommCount); 0 without a communicator */
+int cem_planner_comm_ranks(const cem_planner_t *h, int32_t *n_ranks_out);
 int cem_plan_exchange(cem_planner_t *h);
 /* 0: cem_planner_plan launches kernel by kernel; 1: it replays a captured hipGraph; 2: capturing was tried and is not supported
  * with this communicator / runtime (the plan then stays kernel by kernel — same results) */

@@ -39,5 +39,8 @@ if roll:
          'l2_hit_rate': hit / (hit + miss) if hit + miss else None,
          'sq_valu_mfma_busy_cycles_per_launch': roll.get('SQ_VALU_MFMA_BUSY_CYCLES'),
          'source': 'rocprofv3 --pmc, separate passes of `%s`' % cmd}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench                                   # the hash of the device sources this profile is of (bench.py checks it)
+    t['source_sha16'] = bench.source_sha16()
     json.dump(t, open(os.path.join(out, 'traffic.json'), 'w'), indent=1)
     print(json.dumps(t))

@@ -114,3 +114,48 @@ def scorer_problem(case, obs_dim=60, seed=31, E=5):
                                   reward_goal=spec.get('reward_goal', sp.reward_goal), reward_clip=spec.get('reward_clip', sp.reward_clip),
                                   constrain_indicator=spec.get('constrain_indicator', True), cost_kinds=kinds)
     return pb
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# scores against the oracle, near-threshold candidates included
+# --------------------------------------------------------------------------------------------------------------------
+NEAR = 1e-4          # a `<=` comparison whose operands are closer than this may resolve either way within the rollout's rounding
+
+
+def objective(traj, P, n, sp, variant, post):
+    return o.compute_objective_safe(traj, P, n, sp, post) if variant == 'safe' else o.compute_objective_cem(traj, P, n, sp)
+
+
+def admissible_scores(traj64, P, n, sp, variant, post, delta=2 * NEAR):
+    """The oracle's objective under the ways a trajectory's near-threshold comparisons can legitimately resolve: the nominal
+    thresholds, and the goal threshold / the cost sizes each moved down or up by `delta` (which flips exactly the comparisons whose
+    operands lie within delta of the threshold) — nine score vectors, the nominal one first."""
+    import dataclasses
+    out = []
+    for dg in (0, -1, 1):
+        for dc in (0, -1, 1):
+            v = dataclasses.replace(sp, goal_size=sp.goal_size + dg * delta / 0.8,
+                                    cost_kinds=[(lo, hi, size + dc * delta) for lo, hi, size in sp.cost_kinds])
+            out.append(objective(traj64, P, n, v, variant, post))
+    return out
+
+
+def assert_scores_match_oracle(scores_gpu, traj64, P, n, sp, variant, post, atol, what=''):
+    """Every candidate's GPU score equals the fp64 oracle's within atol + half an fp32 ulp — candidates with a comparison within NEAR
+    of its threshold (rounding may flip it) must equal the oracle's score under one of the admissible resolutions instead of being
+    skipped.  Returns (max error over the clear candidates, number of near-threshold candidates, how many of those took a flipped
+    outcome)."""
+    outs = admissible_scores(traj64, P, n, sp, variant, post)
+    ref = outs[0]
+    allow = atol + 6e-8 * np.abs(ref)
+    err = np.abs(scores_gpu - ref)
+    near = o.threshold_margins(traj64, sp).reshape(P, n).min(axis=0) <= NEAR
+    clear_bad = np.nonzero(~near & (err > allow))[0]
+    assert clear_bad.size == 0, '%s: %d clear candidates differ from the oracle, e.g. %d: gpu %.9g oracle %.9g' % (
+        what, clear_bad.size, clear_bad[0], scores_gpu[clear_bad[0]], ref[clear_bad[0]])
+    best = np.min(np.stack([np.abs(scores_gpu - r) / (atol + 6e-8 * np.abs(r)) for r in outs]), axis=0)
+    near_bad = np.nonzero(near & (best > 1.0))[0]
+    assert near_bad.size == 0, '%s: %d near-threshold candidates equal none of the admissible outcomes, e.g. %d: gpu %.9g nominal %.9g' % (
+        what, near_bad.size, near_bad[0], scores_gpu[near_bad[0]], ref[near_bad[0]])
+    flipped = int((near & (err > allow)).sum())
+    return (float(err[~near].max()) if (~near).any() else 0.0), int(near.sum()), flipped

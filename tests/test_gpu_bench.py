@@ -64,3 +64,23 @@ def test_distributed_leg_host_stepped_fallback():
     r = _json_line(out.stdout)
     _check(r, 5, 2)
     assert r['config']['hip_graph'] is False and 'torch.distributed' in r['config']['exchange']
+
+
+def test_b5_leg_rehearsed_as_one_rank_of_eight():
+    """BASELINE config 5 in bench.py's multi-GPU leg (N = 65536, k = 6554, 65536/G candidates per rank), rehearsed on one GPU:
+    the process plays rank 0 of 8 (8192 candidates, the replicated sample and select over all 65536 scores, the all-gather
+    replaced by a device copy of its shard) under torch.distributed.run with the headline's distributed leg alongside."""
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, CEM_BENCH_FORCE_DIST='1', CEM_BENCH_B5_REHEARSAL='8')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+                          '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '5',
+                          '--warmup', '2', '--no-cpu-baseline'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = _json_line(out.stdout)
+    _check(r, 5, 2)
+    b5 = r['b5']
+    assert b5['n_ranks'] == 8 and b5['candidates_per_rank'] == 8192 and b5['scaling'] == 'strong' and 'N=65536' in b5['workload']
+    assert b5['tiles'] * b5['chunks_per_tile'] * 16 == 5 * 8192 and 'rehearsal' in b5['exchange']
+    assert abs(b5['plans_per_s'] * b5['ms_per_plan'] / 1e3 - 1.0) < 1e-6 and b5['plans_per_s'] > 50
+    assert 0.5 < b5['rollout_frac_of_fp32_mfma_peak_per_rank'] < 1.0 and 20 < b5['select_us_per_iteration'] < 400
+    assert b5['rollout_kernel'].startswith('void cem_rollout_')

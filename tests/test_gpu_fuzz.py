@@ -10,7 +10,7 @@ import pytest
 
 from oracle import cem_oracle as o
 from tests import helpers as hp
-from tests.test_gpu_parity import _run_iteration, _score_err
+from tests.test_gpu_parity import _run_iteration, _score_err, ATOL
 
 pytestmark = pytest.mark.gpu
 # CEM_FUZZ_SCALE=n multiplies the number of seeds of every sweep (a longer one-off hunt; the default suite stays seconds long)
@@ -51,9 +51,7 @@ def test_random_shape_rollout_scores(seed):
     w64 = o.cast_weights(pb['weights'], np.float64)
     ref64, traj64 = o.candidate_scores(pb['state'].astype(np.float64), ref_actions.astype(np.float64), w64, pb['inputs_min'],
                                        pb['inputs_max'], em[0], ocfg, pb['scorer'], return_traj=True)
-    ok = o.threshold_margins(traj64, pb['scorer']).reshape(P, N).min(axis=0) > 1e-4
-    assert ok.mean() > 0.5, ('too many candidates on a threshold for a meaningful case', c)
-    assert _score_err(scores[ok], ref64[ok]) <= 1.0, (c, float(np.abs(scores - ref64)[ok].max()))
+    hp.assert_scores_match_oracle(scores, traj64, P, N, pb['scorer'], c['variant'], c['post'], ATOL, str(c))   # near-threshold candidates included
     pl.close()
 
 

@@ -120,12 +120,8 @@ def test_rollout_scores_match_oracle(variant, P, E, N, H, post):
     w64 = o.cast_weights(pb['weights'], np.float64)
     ref64, traj64 = o.candidate_scores(pb['state'].astype(np.float64), ref_actions.astype(np.float64), w64, pb['inputs_min'],
                                        pb['inputs_max'], em[0], ocfg, pb['scorer'], return_traj=True)
-    margins = o.threshold_margins(traj64, pb['scorer']).reshape(P, N).min(axis=0)
-    ok = margins > 1e-4
-    assert ok.mean() > 0.9, 'too many candidates on a threshold for a meaningful test'
-    err = np.abs(scores - ref64)[ok].max()
-    print('%s scores: max|gpu-f64| = %.3g over %d/%d candidates' % (variant, err, ok.sum(), N))
-    assert _score_err(scores[ok], ref64[ok]) <= 1.0
+    err, n_near, n_flip = hp.assert_scores_match_oracle(scores, traj64, P, N, pb['scorer'], variant, post, ATOL, variant)
+    print('%s scores: max|gpu-f64| = %.3g; %d of %d candidates near a threshold (%d took the flipped outcome)' % (variant, err, n_near, N, n_flip))
     if variant == 'safe':
         assert (ref64 < -50).any() and (ref64 > -50).any(), 'test should see both safe and unsafe candidates'
 
@@ -154,9 +150,9 @@ def test_rollout_scorer_branches(case, variant, obs_dim):
     row_ok = o.threshold_margins(traj64, pb['scorer']) > 1e-4
     ok = row_ok.reshape(P, N).all(axis=0)
     assert ok.mean() > 0.8, 'too many candidates on a threshold for a meaningful test'
-    err = np.abs(scores - ref64)[ok].max()
-    print('%s obs %d %s: max|gpu-f64| = %.3g over %d/%d candidates' % (case, obs_dim, variant, err, ok.sum(), N))
-    assert _score_err(scores[ok], ref64[ok]) <= 1.0
+    err, n_near, n_flip = hp.assert_scores_match_oracle(scores, traj64, P, N, pb['scorer'], variant, ocfg.posterior_mean_threashold, ATOL,
+                                                        '%s obs %d %s' % (case, obs_dim, variant))
+    print('%s obs %d %s: max|gpu-f64| = %.3g; %d of %d candidates near a threshold (%d flipped)' % (case, obs_dim, variant, err, n_near, N, n_flip))
     sp = pb['scorer']
     if variant == 'safe':
         # the masked per-step cost of every row, exactly (small integers): done OR-ed first, then cost(s_t) * (1 - done)
@@ -234,12 +230,9 @@ def test_rollout_scores_random_shapes(seed):
     np.testing.assert_array_equal(actions, ref_actions)
     ref64, traj64 = o.candidate_scores(pb['state'].astype(np.float64), ref_actions.astype(np.float64), o.cast_weights(pb['weights'], np.float64),
                                        pb['inputs_min'], pb['inputs_max'], em[0], ocfg, pb['scorer'], return_traj=True)
-    ok = o.threshold_margins(traj64, pb['scorer']).reshape(P, N).min(axis=0) > 1e-4
-    assert ok.mean() > 0.5
-    err = np.abs(scores - ref64)[ok].max()
-    print('seed %d: O=%d A=%d E=%d P=%d N=%d H=%d %s rc=%d sampling=%s scale=%s: max|gpu-f64| = %.3g over %d/%d'
-          % (seed, O, A, E, P, N, H, variant, rc, sampling, scale, err, ok.sum(), N))
-    assert _score_err(scores[ok], ref64[ok]) <= 1.0
+    err, n_near, n_flip = hp.assert_scores_match_oracle(scores, traj64, P, N, pb['scorer'], variant, 0.3, ATOL, 'seed %d' % seed)
+    print('seed %d: O=%d A=%d E=%d P=%d N=%d H=%d %s rc=%d sampling=%s scale=%s: max|gpu-f64| = %.3g; %d of %d candidates near a threshold, %d took the flipped outcome'
+          % (seed, O, A, E, P, N, H, variant, rc, sampling, scale, err, n_near, N, n_flip))
 
 
 def test_select_is_exact_on_given_scores():
@@ -508,9 +501,9 @@ def test_residency_table_matches_the_runtime():
     lib = _capi.load()
     for nfw in (1, 2):
         for rc in (1, 2, 3, 4):
-            tab, run = C.c_int32(), C.c_int32()
-            _capi.check(lib.cem_rollout_residency(rc, nfw, C.byref(tab), C.byref(run)), 'cem_rollout_residency')
-            assert run.value >= 1 and tab.value == run.value, (nfw, rc, tab.value, run.value)
+            tab, run = (C.c_int32 * 2)(), (C.c_int32 * 2)()      # [one workgroup per tile, pinned + floating-segment form]
+            _capi.check(lib.cem_rollout_residency(rc, nfw, tab, run), 'cem_rollout_residency')
+            assert min(run) >= 1 and list(tab) == list(run), (nfw, rc, list(tab), list(run))
 
 
 def test_errors_are_loud():
@@ -529,6 +522,48 @@ def test_errors_are_loud():
 
 
 # ------------------------------------------------------------------------------------------------- full size
+def _oracle_on_candidates(pl, pb, ocfg, cand, seed, call, P, N, H, A, E):
+    """fp64 oracle of iteration 0 for the given GLOBAL candidate indices (all P particles of each) on the planner's own Philox
+    streams, dumped by cem_fill_noise: (sampled actions [n,H,A], scores [n], trajectories [P*n,H+1,O]).  The rows keep their GLOBAL
+    row ids (p*N + candidate): members, noise rows and action rows are those of the full population."""
+    torch = _torch()
+    cand = np.asarray(cand, np.int64)
+    ea, em, eo = pl.fill_noise(seed=seed, call=call)
+    rows = np.concatenate([p * N + cand for p in range(P)])
+    lb, ub, mu0, sg0 = o.sampling_params(pb['low'], pb['high'])
+    a0 = o.sample_actions(np.broadcast_to(mu0, (H, A)), np.broadcast_to(sg0, (H, A)), lb, ub,
+                          ea[0][torch.as_tensor(cand, device=ea.device)].cpu().numpy())
+    em_sub = em[0][:, torch.as_tensor(rows, device=em.device)].cpu().numpy()
+    del ea, em
+    ref, traj = o.candidate_scores(pb['state'].astype(np.float64), a0.astype(np.float64), o.cast_weights(pb['weights'], np.float64),
+                                   pb['inputs_min'], pb['inputs_max'], em_sub, ocfg, pb['scorer'],
+                                   members=o.member_of_rows(P * N, E, rows), return_traj=True)
+    return a0, ref, traj
+
+
+def _random_candidates(pl, N, n_pick, seed, n_cus=256):
+    """n_pick seeded random candidates of a population, arranged so that they provably cover: candidates with a row in a FLOATING
+    tile of the launch (tile index >= the pinned count; the segment kernel hands those across CUs), candidates of the LAST tiles
+    (last member, ragged tail), the first and the last candidate — the rest uniform over [0, N)."""
+    rng = np.random.default_rng(seed)
+    rc, tiles = pl.tiles()
+    n_seg = pl.segments()[0]
+    n_pinned = (len(tiles) // n_cus) * n_cus if n_seg > 1 else len(tiles)
+    n_off = pl.cfg.rank * (N // pl.cfg.world_size)
+    picked = {n_off, n_off + N // pl.cfg.world_size - 1}
+    floating = tiles[n_pinned:]
+    for td in (floating[rng.choice(len(floating), min(16, len(floating)), replace=False)] if len(floating) else []):
+        picked.add(int(td[3] + rng.integers(td[1])))                 # act_base + a slot of the tile
+    for td in tiles[np.argsort(tiles[:, 4])[-4:]]:                    # the tiles with the highest global row ids (last particle, last member)
+        picked.add(int(td[3] + rng.integers(td[1])))
+    lo, hi = n_off, n_off + N // pl.cfg.world_size
+    while len(picked) < n_pick:
+        picked.add(int(rng.integers(lo, hi)))
+    cand = np.array(sorted(picked))[:n_pick] if len(picked) > n_pick else np.array(sorted(picked))
+    n_float = sum(1 for c in cand if any(td[3] <= c < td[3] + td[1] for td in floating))
+    return cand, n_float, n_seg
+
+
 def test_b2_full_size_properties():
     """BASELINE config B2 (O=60,A=2,K=5,N=2000,H=30): determinism, shard invariance (two half-shards reproduce the
     single-rank scores bit for bit), chunk-size invariance, and sanity of the scores."""
@@ -555,20 +590,18 @@ def test_b2_full_size_properties():
     for rc in (1, 2, 3, 4):                         # every tile size of the obs+act <= 64 kernel family, bit for bit
         _, c3 = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, chunks_per_tile=rc)
         np.testing.assert_array_equal(scores_of(hp.make_planner(pb, c3)), s_a)
-    # a bounded oracle check at full width: the first 64 candidates of iteration 0 on the dumped noise
-    ea, em, eo = pl.fill_noise(seed=3, call=1)
-    sub = 64
-    rows = np.concatenate([p * N + np.arange(sub) for p in range(P)])
-    lb, ub, mu0, sg0 = o.sampling_params(pb['low'], pb['high'])
-    acts = o.sample_actions(np.broadcast_to(mu0, (H, 2)), np.broadcast_to(sg0, (H, 2)), lb, ub, ea[0, :sub].cpu().numpy())
-    ref, traj = o.candidate_scores(pb['state'].astype(np.float64), acts.astype(np.float64), o.cast_weights(pb['weights'], np.float64),
-                                   pb['inputs_min'], pb['inputs_max'], em[0][:, rows].cpu().numpy(), ocfg, pb['scorer'],
-                                   members=o.member_of_rows(P * N, E, rows), return_traj=True)
-    ok = o.threshold_margins(traj, pb['scorer']).reshape(P, sub).min(axis=0) > 1e-4
-    assert ok.sum() > sub // 2
-    err = np.abs(s_a[:sub] - ref)[ok].max()
-    print('B2: max|gpu-f64| over %d bounded candidates = %.3g' % (ok.sum(), err))
-    assert err <= FULL_SIZE_ATOL
+    # Oracle check at full width on 64 RANDOM candidates of iteration 0 (dumped noise), both objectives: the subset provably holds
+    # candidates that ran in floating tiles (handed across CUs by cem_rollout_seg_kernel), the last member's tiles and both ends
+    for variant in ('cem', 'safe'):
+        ocv, pcv = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, variant=variant, post=0.3)
+        plv = pl if variant == 'cem' else hp.make_planner(pb, pcv)
+        s_v = s_a if variant == 'cem' else scores_of(plv)
+        cand, n_float, n_seg = _random_candidates(plv, N, 64, seed=17)
+        assert n_seg > 1 and n_float >= 8, 'B2 should launch pinned + floating tiles (%d segments, %d floating candidates)' % (n_seg, n_float)
+        a0, ref, traj = _oracle_on_candidates(plv, pb, ocv, cand, 3, 1, P, N, H, 2, E)
+        err, n_near, n_flip = hp.assert_scores_match_oracle(s_v[cand], traj, P, len(cand), pb['scorer'], variant, 0.3, FULL_SIZE_ATOL, 'B2 ' + variant)
+        print('B2 %s: max|gpu-f64| = %.3g over %d random candidates (%d in floating tiles; %d near a threshold, %d flipped)'
+              % (variant, err, len(cand), n_float, n_near, n_flip))
 
 
 # ------------------------------------------------------------------------------------------------- BASELINE configs
@@ -649,21 +682,11 @@ def test_large_baseline_configs_properties(name, O, A, K, N, H):
     for rc in ((1, 2, 3, 4) if name == 'B4' else (2,)):   # every tile size of the obs+act > 64 kernel family (B4), bit for bit
         _, c3 = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, chunks_per_tile=rc)
         np.testing.assert_array_equal(scores_of(hp.make_planner(pb, c3)), s1)
-    # bounded oracle check: the first 32 candidates on the dumped noise of iteration 0
-    ea, em, eo = pl.fill_noise(seed=5, call=2)
-    sub = 32
-    rows = np.concatenate([p * N + np.arange(sub) for p in range(P)])
-    lb, ub, mu0, sg0 = o.sampling_params(pb['low'], pb['high'])
-    a0 = o.sample_actions(np.broadcast_to(mu0, (H, A)), np.broadcast_to(sg0, (H, A)), lb, ub, ea[0, :sub].cpu().numpy())
-    np.testing.assert_array_equal(a0, acts[:sub]) if False else None      # actions() now holds iteration 1's samples
-    ref, traj = o.candidate_scores(pb['state'].astype(np.float64), a0.astype(np.float64), o.cast_weights(pb['weights'], np.float64),
-                                   pb['inputs_min'], pb['inputs_max'], em[0][:, rows].cpu().numpy(), ocfg, pb['scorer'],
-                                   members=o.member_of_rows(P * N, E, rows), return_traj=True)
-    ok = o.threshold_margins(traj, pb['scorer']).reshape(P, sub).min(axis=0) > 1e-4
-    assert ok.sum() > sub // 2
-    err = np.abs(s1[:sub] - ref)[ok].max()
-    print('%s: max|gpu-f64| over %d bounded candidates = %.3g' % (name, ok.sum(), err))
-    assert err <= FULL_SIZE_ATOL
+    # oracle check at full width on 48 RANDOM candidates (first / last candidate, last member's tiles, floating tiles if any)
+    cand, n_float, n_seg = _random_candidates(pl, N, 48, seed=23)
+    a0, ref, traj = _oracle_on_candidates(pl, pb, ocfg, cand, 5, 2, P, N, H, A, E)
+    err, n_near, n_flip = hp.assert_scores_match_oracle(s1[cand], traj, P, len(cand), pb['scorer'], 'cem', 0.3, FULL_SIZE_ATOL, name)
+    print('%s: max|gpu-f64| = %.3g over %d random candidates (%d near a threshold, %d flipped)' % (name, err, len(cand), n_near, n_flip))
 
 
 def test_b5_sharded_population_on_one_gpu():
@@ -711,23 +734,25 @@ def test_b5_sharded_population_on_one_gpu():
     j = o.best_of_elite(s1, ref_elite)
     assert sc == s1[j] and it == 1
     np.testing.assert_array_equal(a, acts[j, 0])
-    # (c) bounded oracle check: the first 32 candidates on the dumped noise
-    ea, em, eo = pl.fill_noise(seed=9, call=4)
-    sub = 32
-    rows = np.concatenate([p * N + np.arange(sub) for p in range(P)])
-    lb, ub, mu0, sg0 = o.sampling_params(pb['low'], pb['high'])
-    a0 = o.sample_actions(np.broadcast_to(mu0, (H, 2)), np.broadcast_to(sg0, (H, 2)), lb, ub, ea[0, :sub].cpu().numpy())
-    np.testing.assert_array_equal(a0, acts[:sub])
-    em_sub = em[0][:, torch.as_tensor(rows, device=em.device)].cpu().numpy()
-    del ea, em
-    ref, traj = o.candidate_scores(pb['state'].astype(np.float64), a0.astype(np.float64), o.cast_weights(pb['weights'], np.float64),
-                                   pb['inputs_min'], pb['inputs_max'], em_sub, ocfg, pb['scorer'],
-                                   members=o.member_of_rows(P * N, E, rows), return_traj=True)
-    ok = o.threshold_margins(traj, pb['scorer']).reshape(P, sub).min(axis=0) > 1e-4
-    assert ok.sum() > sub // 2
-    err = np.abs(s1[:sub] - ref)[ok].max()
-    print('B5: max|gpu-f64| over %d bounded candidates = %.3g' % (ok.sum(), err))
-    assert err <= FULL_SIZE_ATOL
+    # (c) oracle check at full width on RANDOM candidates: 40 over the whole population from the single-rank handle, and 6 from
+    #     each of rank shards 1, 4 and 7 checked on THAT rank's own scores (its tiles, Philox rows and members are keyed on global
+    #     indices: a defect in a shard's noise_row_base / act_base would show here, not only in the shard == single-rank comparison)
+    cand, n_float, n_seg = _random_candidates(pl, N, 40, seed=29)
+    a0, ref, traj = _oracle_on_candidates(pl, pb, ocfg, cand, 9, 4, P, N, H, 2, E)
+    np.testing.assert_array_equal(a0, acts[cand])
+    err, n_near, n_flip = hp.assert_scores_match_oracle(s1[cand], traj, P, len(cand), pb['scorer'], 'cem', 0.3, FULL_SIZE_ATOL, 'B5')
+    print('B5: max|gpu-f64| = %.3g over %d random candidates (%d near a threshold, %d flipped)' % (err, len(cand), n_near, n_flip))
+    for r in (1, 4, 7):
+        _, c8 = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, world_size=8, rank=r)
+        p8 = hp.make_planner(pb, c8)
+        s8 = scores_of(p8)
+        p8.plan_end(eps_out=np.zeros(2, np.float32))
+        cand8, _, _ = _random_candidates(p8, N, 6, seed=31 + r)
+        assert cand8.min() >= r * (N // 8) and cand8.max() < (r + 1) * (N // 8)
+        _, ref8, traj8 = _oracle_on_candidates(p8, pb, ocfg, cand8, 9, 4, P, N, H, 2, E)
+        e8, _, _ = hp.assert_scores_match_oracle(s8[cand8 - r * (N // 8)], traj8, P, len(cand8), pb['scorer'], 'cem', 0.3, FULL_SIZE_ATOL, 'B5 rank %d' % r)
+        print('B5 rank %d: max|gpu-f64| = %.3g over its own candidates %s' % (r, e8, cand8.tolist()))
+        p8.close()
 
 
 # ------------------------------------------------------------------------------------------------- standalone ops
@@ -929,8 +954,7 @@ def test_narrow_hidden_layers_run_zero_padded(units):
     pl.plan_end()
     ref64, traj64 = o.candidate_scores(pb['state'].astype(np.float64), actions.astype(np.float64), o.cast_weights(pb['weights'], np.float64),
                                        pb['inputs_min'], pb['inputs_max'], em[0], ocfg, pb['scorer'], return_traj=True)
-    ok = o.threshold_margins(traj64, pb['scorer']).reshape(P, N).min(axis=0) > 1e-4
-    assert ok.mean() > 0.8 and _score_err(scores[ok], ref64[ok]) <= 1.0
+    hp.assert_scores_match_oracle(scores, traj64, P, N, pb['scorer'], 'safe', 0.5, ATOL, 'wide units %d' % units)
     a, s, it = pl.plan(pb['state'], eps_act=ea, eps_model=em, eps_out=eo)
     ra, rs, rit = o.do_generate_action(pb['state'], pb['weights'], pb['inputs_min'], pb['inputs_max'], pb['low'], pb['high'],
                                        ea, em, eo, ocfg, pb['scorer'])
