@@ -70,7 +70,7 @@ int validate(const cem_config_t *c)
     if (c->variant != CEM_VARIANT_CEM && c->variant != CEM_VARIANT_SAFE) return CEM_ERR_INVALID_ARG;
     if (c->chunks_per_tile < 0 || c->chunks_per_tile > 4) return CEM_ERR_INVALID_ARG;
     if (c->rollout_segments < 0 || c->rollout_segments > 64) return CEM_ERR_INVALID_ARG;
-    if (c->select_mode < 0 || c->select_mode > 2) return CEM_ERR_INVALID_ARG;
+    if (c->select_mode < 0 || c->select_mode > 3) return CEM_ERR_INVALID_ARG;
     if ((long long)c->particles * c->n_samples > (1ll << 30)) return CEM_ERR_UNSUPPORTED;
     return CEM_OK;
 }
@@ -326,8 +326,11 @@ double tile_plan_cost(const Dims &d, int rc, size_t n_tiles, int requested_segme
     const int S = segments_for(d, rc, n_tiles, requested_segments);
     const double L = (double)n_tiles / kNumCUs;
     const long per_cu = (long)((n_tiles + kNumCUs - 1) / kNumCUs);
-    if (S > 1 && n_tiles > (size_t)kNumCUs)       // pinned tiles + floating segments: every CU carries the mean load
+    if (S > 1 && n_tiles > (size_t)kNumCUs) {     // pinned tiles + floating segments: every CU carries the mean load
+        if (n_tiles < (size_t)2 * kNumCUs)        // ONE pinned tile per CU runs without a partner and the floaters' chains set the time
+            return (double)rc * L * kChunkStart[d.NFW - 1][rc - 1][0] * 1.35;       // (B2 at rc 2: 0.53 ms for 1.23 x 2 chunks per CU, round 3)
         return (double)rc * L * kChunkStart[d.NFW - 1][rc - 1][std::min<long>(per_cu, 3) - 1] * kFloatFactor;
+    }
     return cu_cost(d.NFW, rc, per_cu, resident_workgroups(d.NFW, rc, false));
 }
 
@@ -476,6 +479,7 @@ struct cem_planner {
     int plans_since_comm;                    // the first plan after comm_init runs eagerly (RCCL sets itself up lazily), then the graph is captured
     bool graph_failed;                       // capture with the collective did not work on this stack: stay eager
     size_t sel_dyn_limit;                    // dynamic-LDS allowance of the select kernels on this handle's device
+    bool sel_zeroed;                         // the multi-workgroup select's histograms / barrier counter were cleared by this iteration's reduce kernel
     // grow-only device scratch of the standalone ops (unfold_sequences tiles + returns, compute_objective returns + costs)
     char *scratch; size_t scratch_bytes;
     std::vector<float> h_etab;               // host copy of RolloutParams::etab ([E][CEM_ET_ROWS + L][128]); re-uploaded whole by create / set_weights / set_normaliser
@@ -598,7 +602,7 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
     h->graph = nullptr; h->gexec = nullptr; h->graph_ready = false;
     h->comm = nullptr; h->plans_since_comm = 0; h->graph_failed = false;
     h->h_ctrl = nullptr; h->h_result = nullptr;
-    h->scratch = nullptr; h->scratch_bytes = 0;
+    h->scratch = nullptr; h->scratch_bytes = 0; h->sel_zeroed = false;
     // every failure from here on frees what was acquired and reports the HIP code
     auto fail = [&](int status) {
         g_last_hip = (int)hipGetLastError();
@@ -891,6 +895,7 @@ int enqueue_rollout(cem_planner *h, int it)
     ReduceParams qp{}; qp.ret = rp.ret; qp.costs = rp.costs; qp.scores = (float *)(ws + l.scores_local); qp.ctrl = sp.ctrl;
     qp.Nloc = d.Nloc; qp.P = d.P; qp.H = d.H; qp.variant = h->cfg.variant; qp.check_done = 1;
     qp.alpha = h->alpha; qp.beta = h->beta; qp.thr = h->cfg.posterior_mean_threashold;
+    qp.zero = (uint32_t *)(ws + l.ms_hist); qp.zero_n = (3 * CEM_MS_BINS * 4 + 256) / 4; h->sel_zeroed = true;     // for this iteration's multi-workgroup select
     hipLaunchKernelGGL(cem_reduce_kernel, dim3((d.Nloc + 63) / 64), dim3(CEM_REDUCE_THREADS), 0, h->stream, qp);
     HIPCHK(hipGetLastError());
     return CEM_OK;
@@ -908,26 +913,43 @@ int enqueue_select(cem_planner *h, int it)
     size_t lds = (size_t)((d.k + 3) & ~3) * 4 + (size_t)2 * d.H * d.A * 4;
     const size_t dyn_limit = h->sel_dyn_limit;          // asked from the runtime at create(), per device
     const bool cache = lds + (size_t)d.N * 4 <= dyn_limit;
-    // Populations whose keys do not fit the LDS of one workgroup go through the multi-workgroup chain (cem_mpc.h select_mode)
-    const bool multi = h->cfg.select_mode == 2 || (h->cfg.select_mode == 0 && !cache);
+    // Large populations (the replicated select of a many-GPU plan) go through multi-workgroup kernels (cem_mpc.h select_mode):
+    // the fused form (one launch, grid barriers) whenever all its ceil(N / 4096) workgroups are resident at once, the eight-launch
+    // chain beyond that (more workgroups than CUs), the one-workgroup kernel for populations it still serves faster.  Measured
+    // (profiles/r03_select_forms.txt, us per select at N = 8000 / 16000 / 40000 / 65536): one workgroup 27 / 44 / 111 / 171, chain
+    // 68 / 71 / 78 / 83, fused 60 / 61 / 69 / 76 — a grid barrier is an atomic and a poll at the device coherence point (~4 us with
+    // the XCDs' L2s not coherent with each other), hardly cheaper than a kernel boundary inside a graph: the cross-over with the
+    // one-workgroup kernel stays near 24 000 keys.
+    const int G = (d.N + CEM_MS_KEYS - 1) / CEM_MS_KEYS;
+    const bool can_fuse = G <= num_cus();
+    int mode = h->cfg.select_mode;
+    if (mode == 0) mode = (d.N >= 24000 || !cache) ? (can_fuse ? 3 : 2) : 1;
+    if (mode == 3 && !can_fuse) mode = 2;
     size_t e0 = 0;
     if (h->timing) { e0 = h->ev_kind.size() * 2; h->ev_kind.push_back({(int)e0, 1}); hipEventRecord(get_event(h, e0), h->stream); }
-    if (multi) {
+    if (mode >= 2) {
         MSelParams m{}; m.scores = p.scores; m.actions = p.actions; m.musig = p.musig; m.ctrl = p.ctrl; m.elite_idx = p.elite_idx;
         m.hist = (uint32_t *)(ws + l.ms_hist); m.sel = (uint32_t *)(ws + l.ms_sel); m.wg_counts = (uint32_t *)(ws + l.ms_counts);
+        m.bar = m.sel + 8;
         m.best_sc = (float *)(ws + l.ms_best_sc); m.best_ix = (int32_t *)(ws + l.ms_best_ix);
         m.part = (float *)(ws + l.ms_part); m.colmean = (float *)(ws + l.ms_colmean);
         m.N = d.N; m.k = d.k; m.HA = p.HA; m.A = d.A; m.check_done = 1; m.smoothing = p.smoothing; m.one_minus_smoothing = p.one_minus_smoothing; m.threshold = p.threshold;
-        m.G = (d.N + CEM_MS_KEYS - 1) / CEM_MS_KEYS; m.G2 = (d.k + CEM_MS_EPG - 1) / CEM_MS_EPG;
-        HIPCHK(hipMemsetAsync(m.hist, 0, 3 * CEM_MS_BINS * 4, h->stream));
-        hipLaunchKernelGGL(cem_msel_hist_kernel<0>, dim3(m.G), dim3(1024), 0, h->stream, m);
-        hipLaunchKernelGGL(cem_msel_hist_kernel<1>, dim3(m.G), dim3(1024), 0, h->stream, m);
-        hipLaunchKernelGGL(cem_msel_hist_kernel<2>, dim3(m.G), dim3(1024), 0, h->stream, m);
-        hipLaunchKernelGGL(cem_msel_count_kernel, dim3(m.G), dim3(1024), 0, h->stream, m);
-        hipLaunchKernelGGL(cem_msel_compact_kernel, dim3(m.G), dim3(1024), 0, h->stream, m);
-        hipLaunchKernelGGL(cem_msel_moments_kernel<0>, dim3(m.G2), dim3(256), 0, h->stream, m);
-        hipLaunchKernelGGL(cem_msel_moments_kernel<1>, dim3(m.G2), dim3(256), 0, h->stream, m);
-        hipLaunchKernelGGL(cem_msel_final_kernel, dim3(1), dim3(256), 0, h->stream, m);
+        m.G = G; m.G2 = (d.k + CEM_MS_EPG - 1) / CEM_MS_EPG;
+        // the histograms and the barrier counter (adjacent in the workspace) start at zero; within a plan the reduce kernel of the
+        // same iteration has already cleared them (ReduceParams::zero), this memset covers a select called on its own
+        if (!h->sel_zeroed) HIPCHK(hipMemsetAsync(m.hist, 0, 3 * CEM_MS_BINS * 4 + 256, h->stream));
+        h->sel_zeroed = false;
+        if (mode == 3) hipLaunchKernelGGL(cem_msel_fused_kernel, dim3(m.G), dim3(1024), 0, h->stream, m);
+        else {
+            hipLaunchKernelGGL(cem_msel_hist_kernel<0>, dim3(m.G), dim3(1024), 0, h->stream, m);
+            hipLaunchKernelGGL(cem_msel_hist_kernel<1>, dim3(m.G), dim3(1024), 0, h->stream, m);
+            hipLaunchKernelGGL(cem_msel_hist_kernel<2>, dim3(m.G), dim3(1024), 0, h->stream, m);
+            hipLaunchKernelGGL(cem_msel_count_kernel, dim3(m.G), dim3(1024), 0, h->stream, m);
+            hipLaunchKernelGGL(cem_msel_compact_kernel, dim3(m.G), dim3(1024), 0, h->stream, m);
+            hipLaunchKernelGGL(cem_msel_moments_kernel<0>, dim3(m.G2), dim3(256), 0, h->stream, m);
+            hipLaunchKernelGGL(cem_msel_moments_kernel<1>, dim3(m.G2), dim3(256), 0, h->stream, m);
+            hipLaunchKernelGGL(cem_msel_final_kernel, dim3(1), dim3(256), 0, h->stream, m);
+        }
     } else {
         if (cache) lds += (size_t)d.N * 4;
         if (cache) hipLaunchKernelGGL(cem_select_kernel<true>, dim3(1), dim3(1024), lds, h->stream, p);

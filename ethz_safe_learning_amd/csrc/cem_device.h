@@ -870,6 +870,7 @@ struct ReduceParams {
     const float *ret; const uint8_t *costs; float *scores; const CtrlBlock *ctrl;
     int32_t Nloc, P, H, variant, check_done;
     float alpha, beta, thr;
+    uint32_t *zero; int32_t zero_n;        // words block 0 clears for the multi-workgroup select that follows (digit histograms + barrier counter), or null
 };
 
 // One block = 64 candidates x 16 waves.  Wave w counts the particle costs of steps t = w, w+16, ... (byte loads,
@@ -880,6 +881,7 @@ __global__ __launch_bounds__(CEM_REDUCE_THREADS) void cem_reduce_kernel(const Re
 {
     __shared__ int32_t unsafe_w[16][64];
     if (p.check_done && p.ctrl->done) return;
+    if (p.zero && blockIdx.x == 0) for (int i = threadIdx.x; i < p.zero_n; i += CEM_REDUCE_THREADS) p.zero[i] = 0u;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + lane;
     const bool live = n < p.Nloc;
@@ -1398,14 +1400,21 @@ struct MSelParams {
     float *colmean;                   // [HA] elite mean, later the smoothed sigma
     int32_t N, k, HA, A, check_done, G, G2;
     float smoothing, one_minus_smoothing, threshold;   // one_minus_smoothing = fl32(1.0 - smoothing) rounded once, as cem_mpc.py:64-65 does
+    uint32_t *bar;                    // cem_msel_fused_kernel: arrival counter of its grid barriers (zeroed with the histograms)
 };
 
 // block-wide (1024 threads): the bin b with ge[b] >= need > ge[b + 1], ge[b] = #keys in bins >= b; returns (b, need - ge[b + 1])
+// COHERENT: the histogram was written by other workgroups of the SAME kernel (atomics at the device coherence point): read it there too
+template <bool COHERENT = false>
 __device__ __forceinline__ void cem_ms_find(const uint32_t *h, const int nbins, const uint32_t need, uint32_t *sh /* [20] */, uint32_t &bin, uint32_t &need_next)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b0 = 2 * tid, b1 = 2 * tid + 1;
-    const uint32_t h0 = b0 < nbins ? h[b0] : 0u, h1 = b1 < nbins ? h[b1] : 0u;
+    uint32_t h0 = 0u, h1 = 0u;
+    if (COHERENT) {
+        if (b0 < nbins) h0 = __hip_atomic_load(h + b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b1 < nbins) h1 = __hip_atomic_load(h + b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else { h0 = b0 < nbins ? h[b0] : 0u; h1 = b1 < nbins ? h[b1] : 0u; }
     const uint32_t tot = h0 + h1;
     uint32_t inc = tot;                                   // inclusive prefix over lower thread ids
 #pragma unroll
@@ -1610,6 +1619,211 @@ __global__ __launch_bounds__(256) void cem_msel_final_kernel(const MSelParams p)
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// The chain above as ONE launch (round 3): the same phases, the same per-phase arithmetic and summation orders (elite set, best
+// action, mu and sigma are bit-identical to the chain's), separated by grid barriers instead of kernel boundaries.  The chain's
+// eight launches cost a fixed ~40 us, which made it lose to the one-workgroup kernel below ~30 000 keys; a grid barrier is one
+// atomic and a short poll.  A thread keeps its four keys in registers across all phases (the chain re-reads the scores three
+// times).  All G = ceil(N / 4096) workgroups must be resident at once: the host only takes this form when G <= the CU count
+// (one 1024-thread workgroup always fits a CU), and every poll is bounded — a barrier that does not complete sets ctrl->fault
+// (the plan then fails with CEM_ERR_DEVICE) instead of hanging the device.
+// Data that crosses workgroups INSIDE the launch (histograms, slice counts, the elite list, moment partial sums, slice bests)
+// is written and read at the device coherence point (agent-scope relaxed atomics = sc1 accesses; no cache maintenance), every
+// wave drains its stores (s_waitcnt vmcnt(0)) before its workgroup arrives at a barrier: the XCDs' L2s are not coherent with
+// each other for plain accesses (MI355X_MICROARCH.md, correctness boundaries).
+// ---------------------------------------------------------------------------------------------------------
+#define CEM_GRID_SPIN_LIMIT (1u << 22)
+__device__ __forceinline__ void cem_grid_barrier(uint32_t *ctr, const uint32_t target, CtrlBlock *ctrl)
+{
+    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): this wave's sc1 stores / atomics are acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < CEM_GRID_SPIN_LIMIT) __builtin_amdgcn_s_sleep(1);
+        if (spins >= CEM_GRID_SPIN_LIMIT) atomicOr(&ctrl->fault, 2);
+    }
+    __syncthreads();
+}
+#define CEM_LDC(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define CEM_STC(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+__global__ __launch_bounds__(1024) void cem_msel_fused_kernel(const MSelParams p)
+{
+    __shared__ uint32_t lh[CEM_MS_BINS];
+    __shared__ uint32_t sh[20];
+    __shared__ uint32_t wsum[2][16];
+    __shared__ uint32_t base[2];
+    __shared__ float bsc[16];
+    __shared__ int bix[16];
+    __shared__ float red[4][4][64];
+    if (p.check_done && p.ctrl->done) return;             // uniform over the grid: set by the previous iteration's tail
+    const int tid = threadIdx.x;
+    const uint32_t G = (uint32_t)p.G;
+    uint32_t phase = 0;
+
+    // this thread's four keys (consecutive candidates: ascending order inside the thread, the thread order = candidate order)
+    uint32_t key[4]; float sc[4];
+    const int i0 = blockIdx.x * CEM_MS_KEYS + 4 * tid;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sc[j] = i0 + j < p.N ? p.scores[i0 + j] : 0.f; key[j] = i0 + j < p.N ? cem_f2key(sc[j]) : 0u; }
+
+    // ---- three digit histograms (11 + 11 + 10 bits) of the order-preserving keys: per-workgroup LDS histogram -> global atomics
+    uint32_t need = (uint32_t)p.k, b0 = 0, b1 = 0, b2 = 0;
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        if (pass == 1) cem_ms_find<true>(p.hist, CEM_MS_BINS, need, sh, b0, need);
+        if (pass == 2) cem_ms_find<true>(p.hist + CEM_MS_BINS, CEM_MS_BINS, need, sh, b1, need);
+        for (int b = tid; b < CEM_MS_BINS; b += 1024) lh[b] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < p.N) {
+                if (pass == 0) atomicAdd(&lh[key[j] >> 21], 1u);
+                else if (pass == 1) { if ((key[j] >> 21) == b0) atomicAdd(&lh[(key[j] >> 10) & 2047u], 1u); }
+                else { if ((key[j] >> 10) == ((b0 << 11) | b1)) atomicAdd(&lh[key[j] & 1023u], 1u); }
+            }
+        __syncthreads();
+        for (int b = tid; b < CEM_MS_BINS; b += 1024) { const uint32_t c = lh[b]; if (c) atomicAdd(&p.hist[pass * CEM_MS_BINS + b], c); }
+        cem_grid_barrier(p.bar, G * ++phase, p.ctrl);
+    }
+    cem_ms_find<true>(p.hist + 2 * CEM_MS_BINS, 1024, need, sh, b2, need);
+    const uint32_t T = (b0 << 21) | (b1 << 10) | b2;      // key of the k-th largest score; `need` keys equal to T are taken, lowest index first
+
+    // ---- keys > T / == T per slice
+    uint32_t ngt = 0, neq = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (i0 + j < p.N) { ngt += key[j] > T; neq += key[j] == T; }
+    {
+        uint32_t a = ngt, b = neq;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
+        if ((tid & 63) == 0) { wsum[0][tid >> 6] = a; wsum[1][tid >> 6] = b; }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t x = 0, y = 0;
+            for (int i = 0; i < 16; ++i) { x += wsum[0][i]; y += wsum[1][i]; }
+            CEM_STC(&p.wg_counts[2 * blockIdx.x], x); CEM_STC(&p.wg_counts[2 * blockIdx.x + 1], y);
+        }
+    }
+    cem_grid_barrier(p.bar, G * ++phase, p.ctrl);
+
+    // ---- compaction: elite indices in ascending candidate order, ties lowest index first (tf.nn.top_k); best elite of the slice
+    {
+        uint32_t a = 0, b = 0;
+        for (int g = tid; g < (int)blockIdx.x; g += 1024) { a += CEM_LDC(&p.wg_counts[2 * g]); b += CEM_LDC(&p.wg_counts[2 * g + 1]); }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
+        if ((tid & 63) == 0) { wsum[0][tid >> 6] = a; wsum[1][tid >> 6] = b; }
+        __syncthreads();
+        if (tid == 0) { uint32_t x = 0, y = 0; for (int i = 0; i < 16; ++i) { x += wsum[0][i]; y += wsum[1][i]; } base[0] = x; base[1] = y; }
+        __syncthreads();
+    }
+    {
+        const uint32_t gt_before = base[0], eq_before = base[1];
+        __syncthreads();
+        uint32_t pre_gt, pre_eq;
+        cem_block_excl_scan2(ngt, neq, wsum, pre_gt, pre_eq);
+        uint32_t eqr = eq_before + pre_eq;
+        uint32_t pos = gt_before + pre_gt + (eqr < need ? eqr : need);
+        float bs = -__builtin_inff(); int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < p.N) {
+                bool take = key[j] > T;
+                if (key[j] == T) { take = eqr < need; ++eqr; }
+                if (take) {
+                    CEM_STC(&p.elite_idx[pos], i0 + j); ++pos;
+                    if (bi == 0x7fffffff || sc[j] > bs) { bs = sc[j]; bi = i0 + j; }          // ascending i: the first maximum is the lowest index
+                }
+            }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float os = __shfl_xor(bs, d); const int oi = __shfl_xor(bi, d);
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { bsc[tid >> 6] = bs; bix[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 1; i < 16; ++i) { const float os = bsc[i]; const int oi = bix[i]; if (oi != 0x7fffffff && (bi == 0x7fffffff || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; } }
+            CEM_STC(&p.best_sc[blockIdx.x], bs); CEM_STC(&p.best_ix[blockIdx.x], bi);
+        }
+    }
+    cem_grid_barrier(p.bar, G * ++phase, p.ctrl);
+
+    // ---- moments over the elite set (tf.nn.moments: mean, then mean squared difference): the chain's decomposition — groups of
+    //      256 elites, four sub-sums per group added in order 0..3, groups added in group order — with each quarter of a
+    //      workgroup (256 threads) playing one of the chain's moment workgroups
+    const int sb = tid >> 8, t256 = tid & 255, sub = t256 >> 6, lc = t256 & 63;
+    const float fk = (float)p.k;
+    const int rounds = (p.G2 + (int)G * 4 - 1) / ((int)G * 4);
+#pragma unroll 1
+    for (int ph = 0; ph < 2; ++ph) {
+        for (int rd = 0; rd < rounds; ++rd) {
+            const int g2 = (rd * (int)G + (int)blockIdx.x) * 4 + sb;
+            const bool have = g2 < p.G2;
+            const int e0 = g2 * CEM_MS_EPG, e1 = (e0 + CEM_MS_EPG < p.k) ? e0 + CEM_MS_EPG : p.k;
+            for (int c0 = 0; c0 < p.HA; c0 += 64) {
+                const int col = c0 + lc;
+                const bool live = have && col < p.HA;
+                float mean = 0.f;
+                if (ph == 1 && live) {
+                    float t = 0.f;
+                    for (int g = 0; g < p.G2; ++g) t = t + CEM_LDC(&p.part[(size_t)g * p.HA + col]);
+                    mean = t / fk;
+                    if (g2 == 0 && sub == 0) CEM_STC(&p.colmean[col], mean);
+                }
+                float acc = 0.f;
+                if (live) {
+                    for (int e = e0 + sub; e < e1; e += 32) {                      // 8 gathers in flight
+                        float a[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { const int ee = e + 4 * j; a[j] = ee < e1 ? p.actions[(size_t)CEM_LDC(&p.elite_idx[ee]) * p.HA + col] : 0.f; }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) if (e + 4 * j < e1) acc = ph ? acc + (a[j] - mean) * (a[j] - mean) : acc + a[j];
+                    }
+                }
+                red[sb][sub][lc] = acc;
+                __syncthreads();
+                if (sub == 0 && live) CEM_STC(&p.part[((size_t)ph * p.G2 + g2) * p.HA + col], ((red[sb][0][lc] + red[sb][1][lc]) + red[sb][2][lc]) + red[sb][3][lc]);
+                __syncthreads();
+            }
+        }
+        cem_grid_barrier(p.bar, G * ++phase, p.ctrl);
+    }
+
+    // ---- tail (workgroup 0): smoothing, early stop, best-so-far — cem_msel_final_kernel's statements
+    if (blockIdx.x != 0) return;
+    const float sm = p.smoothing, osm = p.one_minus_smoothing;
+    for (int col = tid; col < p.HA; col += 1024) {
+        float t = 0.f;
+        for (int g = 0; g < p.G2; ++g) t = t + CEM_LDC(&p.part[((size_t)p.G2 + g) * p.HA + col]);
+        const float sd = sqrtf(t / fk);
+        const float nsg = sm * p.musig[p.HA + col] + osm * sd;                   // cem_mpc.py:65
+        p.musig[col] = sm * p.musig[col] + osm * CEM_LDC(&p.colmean[col]);        // cem_mpc.py:64
+        p.musig[p.HA + col] = nsg;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    if (tid == 0) {
+        float ssum = 0.f;
+        for (int i = 0; i < p.HA; ++i) ssum = ssum + p.musig[p.HA + i];
+        p.ctrl->iters = p.ctrl->iters + 1;
+        if (ssum / (float)p.HA <= p.threshold) p.ctrl->done = 1;                         // cem_mpc.py:66-67
+    }
+    if (tid == 64) {
+        float bs = CEM_LDC(&p.best_sc[0]); int bi = CEM_LDC(&p.best_ix[0]);
+        for (int g = 1; g < p.G; ++g) { const float os = CEM_LDC(&p.best_sc[g]); const int oi = CEM_LDC(&p.best_ix[g]); if (oi != 0x7fffffff && (bi == 0x7fffffff || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; } }
+        if (bi != 0x7fffffff && bs > p.ctrl->best_score) {                                // strict (cem_mpc.py:58)
+            for (int a = 0; a < p.A; ++a) p.ctrl->best[a] = p.actions[(size_t)bi * p.HA + a];
+            p.ctrl->best_score = bs;
+        }
+    }
+}
+#undef CEM_LDC
+#undef CEM_STC
 
 struct FinalParams { const CtrlBlock *ctrl; const float *eps_out; float *result; int32_t A; float noise_stddev; };
 

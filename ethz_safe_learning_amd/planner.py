@@ -60,7 +60,7 @@ class PlannerConfig:
     chunks_per_tile: int = 0
     use_graph: bool = False
     rollout_segments: int = 0          # 0 auto, 1 off, n > 1: horizon-segment work queue (cem_mpc.h)
-    select_mode: int = 0               # 0 auto, 1 one-workgroup select, 2 multi-workgroup select chain (cem_mpc.h)
+    select_mode: int = 0               # 0 auto, 1 one-workgroup select, 2 multi-workgroup chain, 3 the chain fused into one launch (cem_mpc.h)
 
 
 def sampling_params(low, high):

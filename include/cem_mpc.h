@@ -103,9 +103,11 @@ typedef struct cem_config {
     int32_t world_size, rank;
     int32_t chunks_per_tile;      /* 0 = auto; 1..4 = 16-row chunks per workgroup tile */
     int32_t use_graph;            /* 1: capture the whole plan in a hipGraph (single-rank, Philox noise only) */
-    int32_t select_mode;          /* 0 = auto; 1 = the one-workgroup select kernel; 2 = the multi-workgroup chain (large populations:
-                                   * the replicated select of a many-GPU plan).  Same elite set, best action and early stop either way;
-                                   * mu / sigma agree to fp32 rounding (the moments are summed in a different, still fixed, order) */
+    int32_t select_mode;          /* 0 = auto; 1 = the one-workgroup select kernel; 2 = the multi-workgroup chain of eight launches; 3 = that
+                                   * chain as ONE launch with grid barriers (needs ceil(N / 4096) <= CUs, else 2 is taken) — what auto picks
+                                   * from 24 000 candidates on (the replicated select of a many-GPU plan; below, mode 1 is faster).  Same elite set, best action and
+                                   * early stop in every mode; 2 and 3 are bit-identical; mu / sigma of 1 vs 2 / 3 agree to fp32 rounding
+                                   * (the moments are summed in a different, still fixed, order) */
     int32_t rollout_segments;     /* 0 = auto; 1 = one workgroup per tile for the whole horizon; n > 1 = the rollout launch is a
                                    * work queue of (tile, horizon/n) items drawn by resident workgroups — evens out CU load when the
                                    * tile count is not a multiple of the CU count; results are bit-identical either way */

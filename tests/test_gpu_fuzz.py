@@ -124,7 +124,7 @@ def _random_plan_case(seed):
     return dict(O=O, A=A, E=E, P=P, N=N, k=min(k, N), H=int(rng.integers(1, 9)), I=int(rng.integers(2, 5)),
                 variant=str(rng.choice(['cem', 'safe'])), smoothing=float(rng.choice([0.0, 0.1, 0.5])),
                 thr=float(rng.choice([-1.0, -1.0, 0.3, 0.6])), noise=float(rng.choice([0.0, 0.05])),
-                select_mode=int(rng.choice([0, 1, 2])), use_graph=False, units=int(rng.choice([64, 64, 192])))
+                select_mode=int(rng.choice([0, 1, 2, 3])), use_graph=False, units=int(rng.choice([64, 64, 192])))
 
 
 @pytest.mark.parametrize('seed', range(24 * SCALE))

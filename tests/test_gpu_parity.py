@@ -259,7 +259,7 @@ def test_select_is_exact_on_given_scores():
     assert s == best_score and it == 1
 
 
-@pytest.mark.parametrize('mode', [1, 2])
+@pytest.mark.parametrize('mode', [1, 2, 3])
 @pytest.mark.parametrize('case', ['ties', 'all_equal', 'k_equals_n', 'negatives_and_inf', 'large', 'n16000', 'n40000', 'k20000'])
 def test_select_edge_cases(case, mode):
     """tf.nn.top_k semantics on hand-made score vectors written straight into the score buffer."""
@@ -270,7 +270,8 @@ def test_select_edge_cases(case, mode):
     N = {'large': 4096, 'n16000': 16000, 'n40000': 40000, 'k20000': 60000}.get(case, 64)
     k = {'ties': 5, 'all_equal': 7, 'k_equals_n': 64, 'negatives_and_inf': 6, 'large': 409, 'n16000': 1600, 'n40000': 4000, 'k20000': 20000}[case]
     H = 3
-    # mode 1: the one-workgroup select kernel; mode 2: the multi-workgroup chain (what large populations take automatically)
+    # mode 1: the one-workgroup select kernel; mode 2: the multi-workgroup chain; mode 3: the chain fused into one launch with grid
+    # barriers (what populations of 24 000 and more take automatically)
     ocfg, pcfg = hp.configs(pb, N=N, H=H, P=5, E=5, k=k, I=1, select_mode=mode)
     pl = hp.make_planner(pb, pcfg)
     ea, em, eo = hp.noise(1, N, H, 2, 5, 60, seed=1)
@@ -303,7 +304,7 @@ def test_select_edge_cases(case, mode):
     np.testing.assert_allclose(ms[1], np.sqrt(var), rtol=2e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize('mode', [0, 1, 2])
+@pytest.mark.parametrize('mode', [0, 1, 2, 3])
 def test_smoothing_blend_rounds_each_factor_once(mode):
     """cem_mpc.py:64-65 at smoothing = 0.09, where fl32(1.0 - s) and 1.0f - fl32(s) differ by one ulp: with a single elite the
     moments are exact (mean = that candidate's actions, variance 0), so the refit is two products and a sum — compared bit for bit
@@ -921,7 +922,7 @@ def test_select_modes_agree_on_a_whole_plan():
     pb = hp.make_problem(seed=91)
     N, H, P, E, k, I = 6000, 12, 5, 5, 600, 6
     res = []
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         _, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, variant='safe', post=0.3, noise=0.0, thr=0.55, smoothing=0.2, select_mode=mode)
         pl = hp.make_planner(pb, pcfg)
         a, s, it = pl.plan(pb['state'], seed=3, call=0)
@@ -933,6 +934,11 @@ def test_select_modes_agree_on_a_whole_plan():
     assert abs(res[0][1] - res[1][1]) <= 2e-5 and res[0][2] == res[1][2] and 1 < res[0][2] <= I
     assert len(np.intersect1d(res[0][3], res[1][3])) >= 0.99 * k
     np.testing.assert_allclose(res[0][4], res[1][4], rtol=1e-4, atol=1e-6)
+    # the fused form keeps the chain's summation orders: the whole plan is bit-identical to the chain's
+    np.testing.assert_array_equal(res[1][0], res[2][0])
+    assert res[1][1] == res[2][1] and res[1][2] == res[2][2]
+    np.testing.assert_array_equal(res[1][3], res[2][3])
+    np.testing.assert_array_equal(res[1][4], res[2][4])
 
 
 @pytest.mark.parametrize('units', [64, 100, 17])
