@@ -28,7 +28,8 @@ class MlpEnsemble(object):
         if act not in ('tf.nn.relu', 'relu'):
             raise NotImplementedError('only the relu activation of config/models.yaml:12 is built into the kernel')
         if float(self.mlp_params.get('dropout_rate', 0.0)) != 0.0:
-            raise NotImplementedError('dropout is identity at inference (mlp_ensemble.py:127); training is not built yet')
+            raise NotImplementedError('dropout_rate != 0 is not built: the device trainer (cem_train_tile.h) has no dropout mask; '
+                                      'config/models.yaml ships 0.0, where the reference\'s Dropout layer is the identity (mlp_ensemble.py:21)')
         rng = np.random.default_rng(seed)
         self._weights = [self._init_member(rng) for _ in range(ensemble_size)]
         self.version = 0

@@ -1,0 +1,81 @@
+"""Build-time checks on the device ISA (no GPU): properties of the generated code that the memory model of the hand-over paths
+depends on and that the compiler is free to break silently.  The kernels are compiled to assembly with the Makefile's own
+flags (hipcc -S --cuda-device-only, ~25 s; cached under /tmp on the hash of the device sources)."""
+import hashlib
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, 'ethz_safe_learning_amd', 'csrc')
+
+
+def _makefile_flags():
+    mk = open(os.path.join(CSRC, 'Makefile')).read()
+    flags = re.search(r'^FLAGS\s*:=\s*(.*)$', mk, re.M).group(1).replace('$(ARCH)', 'gfx950').split()
+    return [f for f in flags if f not in ('-fPIC', '-shared')]
+
+
+@pytest.fixture(scope='module')
+def isa():
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith(('.h', '.hip')) or f == 'Makefile':
+            h.update(open(os.path.join(CSRC, f), 'rb').read())
+    h.update(open(os.path.join(ROOT, 'include', 'cem_mpc.h'), 'rb').read())
+    out = '/tmp/cem_isa_%s.s' % h.hexdigest()[:16]
+    if not os.path.exists(out):
+        r = subprocess.run([hipcc] + _makefile_flags() + ['-S', '--cuda-device-only', '-o', out + '.tmp', os.path.join(CSRC, 'cem_capi.hip')],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        os.replace(out + '.tmp', out)
+    return open(out).read()
+
+
+def _kernel_bodies(isa, pattern):
+    """{mangled name: [instruction lines]} of the kernels whose name matches."""
+    out = {}
+    for m in re.finditer(r'^(_Z\w+):.*?\n(.*?)^\s*s_endpgm', isa, re.M | re.S):
+        if re.search(pattern, m.group(1)):
+            out[m.group(1)] = [l.split(';')[0].strip() for l in m.group(2).splitlines() if l.strip() and not l.lstrip().startswith((';', '.'))]
+    return out
+
+
+def test_floating_segment_hand_over_drains_its_stores_before_the_flag(isa):
+    """cem_rollout_seg_kernel: a tile's state crosses CUs (and XCDs, whose L2s are not coherent with each other) as sc1 stores
+    followed by a flag.  Every wave must wait for the acknowledgement of ITS OWN stores (s_waitcnt vmcnt(0)) before the workgroup
+    barrier that precedes the flag store: s_barrier does not drain stores on gfx940+, and a workgroup-scope fence compiles to no
+    wait (round 2's code relied on both).  Checked for all eight <chunks, input blocks> instantiations."""
+    bodies = _kernel_bodies(isa, r'cem_rollout_seg_kernel')
+    assert len(bodies) == 8, sorted(bodies)
+    for name, ins in bodies.items():
+        stores = [i for i, l in enumerate(ins) if l.startswith('buffer_store_dwordx4') and l.endswith('sc1')]
+        assert stores, name
+        last = stores[-1]
+        bar = next(i for i in range(last, len(ins)) if ins[i].startswith('s_barrier'))
+        between = ins[last + 1:bar]
+        assert any(l.startswith('s_waitcnt') and 'vmcnt(0)' in l for l in between), (name, between)
+        # ... and the flag: an atomic ticket, then the sc1 flag store, after that barrier
+        tail = ins[bar:]
+        assert any(l.startswith('global_atomic_add') for l in tail) and any(l.startswith('global_store_dword') and 'sc1' in l for l in tail), name
+
+
+def test_fused_select_grid_barrier_drains_before_arriving(isa):
+    """cem_msel_fused_kernel: seven grid barriers; before each, every wave's sc1 stores / atomics are acknowledged
+    (s_waitcnt vmcnt(0) directly before the workgroup barrier that precedes the arrival atomic)."""
+    bodies = _kernel_bodies(isa, r'cem_msel_fused_kernel')
+    assert len(bodies) == 1
+    ins = next(iter(bodies.values()))
+    # an arrival = the atomic add that is followed by the polling loop (sc1 load + s_sleep)
+    arrivals = [i for i, l in enumerate(ins) if l.startswith('global_atomic_add') and any(x.startswith('s_sleep') for x in ins[i + 1:i + 20])]
+    assert len(arrivals) >= 4, arrivals      # the phases in loops share code: at least the histogram loop, counts, compaction, moments loop
+    for a in arrivals:
+        bar = max(i for i in range(a) if ins[i].startswith('s_barrier'))
+        assert a - bar < 20, (a, bar)
+        prev = ins[max(0, bar - 3):bar]
+        assert any(x.startswith('s_waitcnt') and 'vmcnt(0)' in x for x in prev), (a, prev)
