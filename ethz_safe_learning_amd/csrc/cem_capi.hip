@@ -223,14 +223,15 @@ void build_plan_tiles(const Dims &d, int rc, std::vector<Tile6> &out)
 // A tile is 16*rc rows of one member; a CU keeps as many workgroups resident as their registers allow.  fp32 MFMA and
 // VALU work add up on a SIMD whichever wave they come from, so a co-resident workgroup cannot hide arithmetic — but it
 // does hide the stalls (barrier skew, LDS and L2 latency at the stage boundaries).  Cost of one 16-row chunk for the whole
-// horizon in ms at H = 30 on MI355X, measured with exactly m tiles per CU (scripts/sweep_chunk_costs.py, round 3:
-// profiles/r03_chunk_costs.jsonl): kChunkStart[nfw][rc][k-1] when k tiles start together on a CU and all stay resident (k up to
-// the residency), kChunkNext[nfw][rc] for every further tile the dispatcher starts as an earlier one retires (fitted to the
-// BASELINE-config sweeps at forced tile sizes, profiles/r03_sweep_forced_chunks.txt: B3 32 and B5 10 chunks per CU, B4 8).
+// horizon in ms at H = 30 on MI355X, measured with exactly m tiles per CU (scripts/sweep_chunk_costs.py, round 3 with the
+// rotating issue priority: profiles/r03_chunk_costs.jsonl): kChunkStart[nfw][rc][k-1] when k tiles start together on a CU and all
+// stay resident (k up to the residency), kChunkNext[nfw][rc] for every further tile the dispatcher starts as an earlier one
+// retires (fitted to m = 6 and to the BASELINE-config sweeps: B3 32, B5 10, B4 8 chunks per CU).  Co-resident tiles now advance
+// together and retire together, so ONE tile more than the residency runs its whole horizon alone: it costs a round of two.
 // Larger tiles re-use each streamed weight group for more rows; smaller ones pack the CUs more evenly and co-reside more easily.
-static const double kChunkStart[2][4][3] = {{{0.2003, 0.1728, 0.1649}, {0.1596, 0.1443, 0.1383}, {0.1493, 0.1376, 0.1376}, {0.1456, 0.1364, 0.1364}},
-                                            {{0.2480, 0.2103, 0.1970}, {0.2122, 0.1908, 0.1908}, {0.1999, 0.1856, 0.1856}, {0.1959, 0.1959, 0.1959}}};
-static const double kChunkNext[2][4] = {{0.1350, 0.1330, 0.1335, 0.1330}, {0.1874, 0.1845, 0.1807, 0.1932}};
+static const double kChunkStart[2][4][3] = {{{0.2034, 0.1732, 0.1596}, {0.1580, 0.1389, 0.1353}, {0.1489, 0.1342, 0.1342}, {0.1462, 0.1331, 0.1331}},
+                                            {{0.2383, 0.2026, 0.1909}, {0.2110, 0.1848, 0.1848}, {0.2000, 0.1824, 0.1824}, {0.2057, 0.2057, 0.2057}}};
+static const double kChunkNext[2][4] = {{0.1340, 0.1340, 0.1335, 0.1320}, {0.1920, 0.1840, 0.1807, 0.1932}};   // (rc 1: B3 / B5 at one-chunk tiles, 0.130 - 0.136; m = 6 alone gives 0.123)
 #define CEM_MAX_DEVICES 64
 // workgroups of a <rc, nfw> tile one CU keeps resident, from the kernels' VGPR counts (512 registers per SIMD lane; round 3:
 // plain kernel 139/159/186/218, 165/217/253/288; segment kernel 144/163/190/223, 171/221/255/292), [form][nfw - 1][rc - 1]
@@ -294,14 +295,15 @@ int num_cus() { return device_facts().cus; }
 // partner and a floater's 30-step chain plus its hand-overs is as long as two whole tiles) and none when the remainder nearly
 // fills the CUs anyway (750 tiles: 0.498 -> 0.492).  Hence: at least two pinned tiles per CU, and a predicted gain of > 4 %.
 static const int kSegMaxSegments = 6, kSegMinSteps = 5;
-static const double kFloatFactor = 0.96;    // pinned + floating launch vs (mean tiles per CU) x the all-resident chunk cost (B2, round 3: 0.3857 ms vs 2.44 x 0.1649)
+static const double kFloatFactor = 0.945;   // pinned + floating launch vs (mean tiles per CU) x the all-resident chunk cost (B2, round 3: 0.3677 ms vs 2.44 x 0.1596)
 
 // cost of `per_cu` tiles of rc chunks queued on one CU that keeps `occ` resident
 double cu_cost(int nfw, int rc, long per_cu, int occ)
 {
     const long k = std::min<long>(per_cu, std::min(occ, 3));
     if (k < 1) return 0.0;
-    return (double)rc * ((double)k * kChunkStart[nfw - 1][rc - 1][k - 1] + (double)(per_cu - k) * kChunkNext[nfw - 1][rc - 1]);
+    const long later = per_cu - k + (per_cu == k + 1 && k > 1 ? 1 : 0);    // one tile beyond the residency: as dear as two (see above)
+    return (double)rc * ((double)k * kChunkStart[nfw - 1][rc - 1][k - 1] + (double)later * kChunkNext[nfw - 1][rc - 1]);
 }
 
 int segments_for(const Dims &d, int rc, size_t n_tiles, int requested)
@@ -317,7 +319,7 @@ int segments_for(const Dims &d, int rc, size_t n_tiles, int requested)
     const double L = (double)n_tiles / kNumCUs;
     const long per_cu = (long)std::ceil(L);
     const double plain = cu_cost(d.NFW, rc, per_cu, occ), floating = (double)rc * L * kChunkStart[d.NFW - 1][rc - 1][std::min<long>(per_cu, 3) - 1] * kFloatFactor;
-    return plain / floating > 1.04 ? S : 1;
+    return plain / floating > 1.10 ? S : 1;      // (a remainder that nearly fills the CUs gains nothing: 750 tiles measured 0.498 -> 0.492 ms in round 2)
 }
 
 double tile_plan_cost(const Dims &d, int rc, size_t n_tiles, int requested_segments)

@@ -269,7 +269,14 @@ struct WRing {
     }
 };
 
-#define CEM_LDS_AHEAD 1
+// groups of lead the LDS reads of the other waves' blocks get over their MFMAs: a group is 8 RC MFMAs = 256 RC cycles
+#ifndef CEM_LDS_AHEAD_RC1
+#define CEM_LDS_AHEAD_RC1 1
+#endif
+#ifndef CEM_LDS_AHEAD_RC2
+#define CEM_LDS_AHEAD_RC2 1
+#endif
+#define CEM_LDS_AHEAD (RC == 1 ? CEM_LDS_AHEAD_RC1 : (RC == 2 ? CEM_LDS_AHEAD_RC2 : 1))
 #define CEM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // One dense stage for this wave: acc{0,1}[c] += W^T-groups . hB.  hB[0..NOWN-1] (the wave's own blocks) are already
@@ -591,7 +598,21 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
     st_[7] = tprev_;
 #endif
 
+    // Issue priority rotates with the step.  Tiles that share a CU's SIMDs are otherwise served oldest-wave-first: the oldest tile
+    // runs nearly as if alone, the others advance in its stalls and reach their barriers wave by wave (three co-started tiles used to
+    // finish at 754 K / 964 K / 1100 K cycles).  With each tile at level (t + dispatch round) mod 3 for step t, every tile gets
+    // steps in which all four of its waves are preferred on all four SIMDs at once, and the CU's tiles advance together:
+    // B2 0.382 -> 0.367 ms, B4 2.49 -> 2.45 ms, B3 / B5 rank +1 % (profiles/r03_ab_priority_rotation.txt; per-stage rotation,
+    // two levels, MFMA-phase-high and epilogue-high were measured too and gain less or lose).  Floating tiles keep level 3.
+    const bool prio_rot = !(SEG && tile_idx >= p.n_pinned);
+    const int prio_r0 = (tile_idx >> 8) % 3;
     for (int t = t_begin; t < t_end; ++t) {
+#ifndef CEM_NO_PRIO_ROTATION
+        if (prio_rot) {
+            const int lvl = (t + prio_r0) % 3;
+            if (lvl == 0) __builtin_amdgcn_s_setprio(0); else if (lvl == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
+        }
+#endif
         // ---- dense layers: h = relu(h W + b)  (mlp_ensemble.py:18-22).  The accumulators start at the bias
         // (x W + b with b added first: same sum, one rounding order apart); the bias of the NEXT layer is requested a
         // whole stage ahead of its use.  Layer 0 is peeled out of the loop: with both stage shapes inside one runtime
