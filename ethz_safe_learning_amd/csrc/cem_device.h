@@ -20,6 +20,11 @@
 // 16-B LDS loads, conflict-free, no shuffles, no transposes.  Weights are pre-packed on the host in
 // A-operand order per (member, wave) as one linear stream and prefetched L2 -> VGPR three groups ahead.
 // The state s_t lives in registers of the wave that owns its 16-feature block for all H steps.
+// fp32 MFMA and VALU instructions share one issue pipe, so everything beside the MFMAs is written to be few instructions: the
+// epilogue (heads -> Normal sample -> state update -> scorer terms -> next scaled input) works on a lane's four features at a
+// time in packed v_pk_{fma,mul,add}_f32 (one issue slot for two elements), per-feature constants come from one per-member table
+// through a single buffer resource, the sampled actions from a padded quad layout (one 16-byte load).  Tiles that share a CU
+// take turns at issue priority (rotating with the step) and at the heavier wave roles (rotating with the tile).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -269,14 +274,11 @@ struct WRing {
     }
 };
 
-// groups of lead the LDS reads of the other waves' blocks get over their MFMAs: a group is 8 RC MFMAs = 256 RC cycles
-#ifndef CEM_LDS_AHEAD_RC1
-#define CEM_LDS_AHEAD_RC1 1
-#endif
-#ifndef CEM_LDS_AHEAD_RC2
-#define CEM_LDS_AHEAD_RC2 1
-#endif
-#define CEM_LDS_AHEAD (RC == 1 ? CEM_LDS_AHEAD_RC1 : (RC == 2 ? CEM_LDS_AHEAD_RC2 : 1))
+// Groups of lead the LDS reads of the other waves' blocks get over their MFMAs (template parameter LA of cem_mfma_stage).  A group
+// is 8 RC MFMAs = 256 RC cycles.  One-chunk tiles of the obs+act <= 64 family read all six blocks right after the barrier
+// (LA 6: B1 -2.6 %, B2 unchanged; 151 VGPRs, still three workgroups per CU); every other form reads one group ahead — more would
+// cost the RC = 2 kernels and the one-chunk obs+act > 64 kernel their third resident workgroup (measured: -3 % at the B5 rank).
+#define CEM_LDS_AHEAD_OF(RC_, NFW_) (((RC_) == 1 && (NFW_) == 1) ? 6 : 1)
 #define CEM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // One dense stage for this wave: acc{0,1}[c] += W^T-groups . hB.  hB[0..NOWN-1] (the wave's own blocks) are already
@@ -287,7 +289,7 @@ struct WRing {
 // kept: eight blocks held in registers across two stages cost the obs+act > 64 kernels their second resident workgroup).
 #define CEM_X_EXCHANGE 1
 #define CEM_X_REREAD 2
-template <int RC, int KF, int NOWN, bool L0IN, int XMODE>
+template <int RC, int KF, int NOWN, bool L0IN, int XMODE, int LA>
 __device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], f4 (&hB)[CEM_NG][RC], WRing &wq,
                                                const char *smem, const int xr, const int lane, const int w)
 {
@@ -300,14 +302,14 @@ __device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], f
         // group of MFMAs eats a full L2 round trip
         __builtin_amdgcn_sched_barrier(0);
         if (XMODE != 0 && P >= 1) {
-            // the other waves' blocks are read just in time, CEM_LDS_AHEAD groups before their MFMAs: all of them at once
+            // the other waves' blocks are read just in time, LA groups before their MFMAs: all of them at once
             // is 24*RC live registers from group 1 on, which at RC = 3 pushes the kernel over the 256 architectural VGPRs
 #ifndef CEM_DBG_NOBARRIER      // (timing-only diagnostic builds may drop the barrier / the LDS reads; never the shipped library)
             if (P == 1 && XMODE == CEM_X_EXCHANGE) __syncthreads();   // every wave's blocks of the previous stage are in LDS
 #endif
 #pragma unroll
             for (int Q = NOWN; Q < KF; ++Q) {
-                const bool now = (P == 1) ? (Q <= 1 + CEM_LDS_AHEAD) : (Q == P + CEM_LDS_AHEAD);
+                const bool now = (P == 1) ? (Q <= 1 + LA) : (Q == P + LA);
                 if (now) {
                     const int F = L0IN ? cem_perm_l0(w, KF / 4, Q) : cem_perm_hidden(w, Q);
 #pragma unroll
@@ -394,21 +396,25 @@ __device__ __forceinline__ void cem_scorer_terms(const f4 sn, const float D, con
 template <int RC, int NFW, int MODE, bool SEG>
 __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *smem, const int tile_idx, const int t_begin, const int t_end)
 {
-    const int tid = threadIdx.x;
+    // The four waves' ROLES (which input / output feature blocks a wave owns, hence its weight stream; who keeps the books) rotate
+    // with the tile: hardware wave v plays logical wave w = (v + tile rotation) mod 4.  The roles are not equally heavy — the
+    // bookkeeping wave has about 70 VALU instructions per step more, and where the observation does not fill every wave's last
+    // input block (obs 100: 7 blocks over 4 waves) one wave skips a whole heads stage (64 RC MFMAs of 704 per step) — and the tiles
+    // that share a CU would otherwise all put their heavy roles on the same SIMDs.  Everything below is in terms of w.
+    const int tid = (int)((threadIdx.x + 64u * (unsigned)((tile_idx + (tile_idx >> 8)) & 3)) & 255u);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int j = lane & 15, q = lane >> 4;
     const TileDesc td = p.tiles[tile_idx];
     const bool resumed = SEG && t_begin > 0;
-    // The reward / cost / done bookkeeping of a tile's rows is one wave's extra work (about 70 VALU instructions per step next to
-    // 330).  Which wave does it depends on the tile, so that the tiles sharing a CU do not all load the same SIMD with it.
-    const int wbk = (tile_idx + (tile_idx >> 8)) & 3;
+    const int wbk = 0;                                   // the logical wave that keeps the tile's reward / cost / done bookkeeping
     // this tile's slot of the hand-over buffer as a buffer resource: [2*NFW*RC][256 threads] f4 + [64 lanes] f4
     const __amdgpu_buffer_rsrc_t seg_rs = __builtin_amdgcn_make_buffer_rsrc(
         SEG ? const_cast<f4 *>(p.seg_state + (size_t)(tile_idx - p.n_pinned) * (2 * NFW * RC * 256 + 64)) : const_cast<f4 *>(p.wpack), 0,
         (2 * NFW * RC * 256 + 64) * 16, 0x00020000);
     const int O = p.O, A = p.A, H = p.H;
     constexpr int XB = RC * CEM_NG * 1024;
+    constexpr int LA = CEM_LDS_AHEAD_OF(RC, NFW);
     float *part = reinterpret_cast<float *>(smem + 2 * XB);
     int xw = 0;                                          // LDS buffer the current stage's outputs go to
     const PhiloxKey key = cem_key(p.ctrl);
@@ -636,7 +642,7 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
             for (int c = 0; c < RC; ++c) { acc0[c] = nb0; acc1[c] = nb1; }
             CEM_NEXT_BIAS(p.L > 1 ? 1 : 0);
             // stage input = previous stage's output buffer = xw ^ XB (the previous stage toggled xw after writing)
-            cem_mfma_stage<RC, 4 * NFW, NFW, true, CEM_X_EXCHANGE>(acc0, acc1, hB, wq, smem, xw ^ XB, lane, w);
+            cem_mfma_stage<RC, 4 * NFW, NFW, true, CEM_X_EXCHANGE, LA>(acc0, acc1, hB, wq, smem, xw ^ XB, lane, w);
             if (!(resumed && t == t_begin)) CEM_BOOKKEEP(t - 1);   // the barrier inside the stage published step t-1's scorer terms (a resumed segment took them from seg_state)
             CEM_RELU_PUBLISH();
             CEM_STAMP(0);
@@ -646,7 +652,7 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
 #pragma unroll
             for (int c = 0; c < RC; ++c) { acc0[c] = nb0; acc1[c] = nb1; }
             CEM_NEXT_BIAS(l + 1 < p.L ? l + 1 : 0);
-            cem_mfma_stage<RC, CEM_NG, 2, false, CEM_X_EXCHANGE>(acc0, acc1, hB, wq, smem, xw ^ XB, lane, w);
+            cem_mfma_stage<RC, CEM_NG, 2, false, CEM_X_EXCHANGE, LA>(acc0, acc1, hB, wq, smem, xw ^ XB, lane, w);
             CEM_RELU_PUBLISH();
             CEM_STAMP(1);
         }
@@ -697,8 +703,8 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
             CEM_STAMP(2);
             // the first heads stage also performs the exchange of the last hidden layer's output
             if (Fo < p.KB_obs) {                                                           // wave-uniform
-                if (i == 0) cem_mfma_stage<RC, CEM_NG, 2, false, CEM_X_EXCHANGE>(accm, accv, hB, wq, smem, xw ^ XB, lane, w);
-                else cem_mfma_stage<RC, CEM_NG, 2, false, CEM_X_REREAD>(accm, accv, hB, wq, smem, xw ^ XB, lane, w);
+                if (i == 0) cem_mfma_stage<RC, CEM_NG, 2, false, CEM_X_EXCHANGE, LA>(accm, accv, hB, wq, smem, xw ^ XB, lane, w);
+                else cem_mfma_stage<RC, CEM_NG, 2, false, CEM_X_REREAD, LA>(accm, accv, hB, wq, smem, xw ^ XB, lane, w);
             } else if (i == 0) {
                 __syncthreads();                      // keep the barrier count of waves without observation features
             }
