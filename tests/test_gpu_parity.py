@@ -735,7 +735,7 @@ def test_b5_sharded_population_on_one_gpu():
     j = o.best_of_elite(s1, ref_elite)
     assert sc == s1[j] and it == 1
     np.testing.assert_array_equal(a, acts[j, 0])
-    # (c) oracle check at full width on RANDOM candidates: 40 over the whole population from the single-rank handle, and 6 from
+    # (c) oracle check at full width on RANDOM candidates: 40 over the whole population from the single-rank handle, and 10 from
     #     each of rank shards 1, 4 and 7 checked on THAT rank's own scores (its tiles, Philox rows and members are keyed on global
     #     indices: a defect in a shard's noise_row_base / act_base would show here, not only in the shard == single-rank comparison)
     cand, n_float, n_seg = _random_candidates(pl, N, 40, seed=29)
@@ -748,7 +748,7 @@ def test_b5_sharded_population_on_one_gpu():
         p8 = hp.make_planner(pb, c8)
         s8 = scores_of(p8)
         p8.plan_end(eps_out=np.zeros(2, np.float32))
-        cand8, _, _ = _random_candidates(p8, N, 6, seed=31 + r)
+        cand8, _, _ = _random_candidates(p8, N, 10, seed=31 + r)       # first / last of the shard, its last tiles, four uniform
         assert cand8.min() >= r * (N // 8) and cand8.max() < (r + 1) * (N // 8)
         _, ref8, traj8 = _oracle_on_candidates(p8, pb, ocfg, cand8, 9, 4, P, N, H, 2, E)
         e8, _, _ = hp.assert_scores_match_oracle(s8[cand8 - r * (N // 8)], traj8, P, len(cand8), pb['scorer'], 'cem', 0.3, FULL_SIZE_ATOL, 'B5 rank %d' % r)
