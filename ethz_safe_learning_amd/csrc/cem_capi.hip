@@ -47,9 +47,12 @@ int validate(const cem_config_t *c)
     if (c->obs_dim + c->act_dim > CEM_U) return CEM_ERR_UNSUPPORTED;
     if (c->n_samples % c->world_size != 0) return CEM_ERR_INVALID_ARG;
     if (((long long)c->particles * c->n_samples) % c->ensemble_size != 0) return CEM_ERR_SPLIT;
-    if (c->n_elite > 24576) return CEM_ERR_UNSUPPORTED;
-    // the select kernel keeps the elite list and two per-(step, action) arrays in dynamic LDS (140 KB available)
-    if ((size_t)((c->n_elite + 3) & ~3) * 4 + (size_t)2 * c->horizon * c->act_dim * 4 > 140 * 1024) return CEM_ERR_UNSUPPORTED;
+    // the ONE-workgroup select kernel keeps the elite list and two per-(step, action) arrays in dynamic LDS (140 KB available, at most
+    // 24576 elites); the multi-workgroup forms (select_mode 2 / 3, automatic from 24 000 candidates) have no such limit
+    if (c->select_mode == 1 || (c->select_mode == 0 && c->n_samples < 24000)) {
+        if (c->n_elite > 24576) return CEM_ERR_UNSUPPORTED;
+        if ((size_t)((c->n_elite + 3) & ~3) * 4 + (size_t)2 * c->horizon * c->act_dim * 4 > 140 * 1024) return CEM_ERR_UNSUPPORTED;
+    }
     if (c->scorer.n_cost_kinds < 0 || c->scorer.n_cost_kinds > CEM_MAX_COST_KINDS) return CEM_ERR_INVALID_ARG;
     {   // scorer slices: inside the observation and non-empty (an empty lidar slice would make closest_distance +inf and rewards NaN)
         const cem_scorer_t &s = c->scorer;
@@ -925,7 +928,7 @@ int enqueue_select(cem_planner *h, int it)
     const int G = (d.N + CEM_MS_KEYS - 1) / CEM_MS_KEYS;
     const bool can_fuse = G <= num_cus();
     int mode = h->cfg.select_mode;
-    if (mode == 0) mode = (d.N >= 24000 || !cache) ? (can_fuse ? 3 : 2) : 1;
+    if (mode == 0) mode = (d.N >= 24000 || !cache) ? (can_fuse ? 3 : 2) : 1;      // (validate() has checked that mode 1 can hold the elite list)
     if (mode == 3 && !can_fuse) mode = 2;
     size_t e0 = 0;
     if (h->timing) { e0 = h->ev_kind.size() * 2; h->ev_kind.push_back({(int)e0, 1}); hipEventRecord(get_event(h, e0), h->stream); }

@@ -260,15 +260,21 @@ def test_select_is_exact_on_given_scores():
 
 
 @pytest.mark.parametrize('mode', [1, 2, 3])
-@pytest.mark.parametrize('case', ['ties', 'all_equal', 'k_equals_n', 'negatives_and_inf', 'large', 'n16000', 'n40000', 'k20000'])
+@pytest.mark.parametrize('case', ['ties', 'all_equal', 'k_equals_n', 'negatives_and_inf', 'large', 'n16000', 'n40000', 'k20000', 'k30000'])
 def test_select_edge_cases(case, mode):
     """tf.nn.top_k semantics on hand-made score vectors written straight into the score buffer."""
     torch = _torch()
     pb = hp.make_problem(seed=42)
     # n16000: the replicated select of an 8-GPU weak-scaled plan (scores staged in 64 KB of LDS); n40000: beyond the LDS cache
     # k20000: an elite list of 80 KB in dynamic LDS on the uncached path
-    N = {'large': 4096, 'n16000': 16000, 'n40000': 40000, 'k20000': 60000}.get(case, 64)
-    k = {'ties': 5, 'all_equal': 7, 'k_equals_n': 64, 'negatives_and_inf': 6, 'large': 409, 'n16000': 1600, 'n40000': 4000, 'k20000': 20000}[case]
+    # k30000: more elites than the one-workgroup kernel's LDS list holds (24576): the multi-workgroup forms only
+    N = {'large': 4096, 'n16000': 16000, 'n40000': 40000, 'k20000': 60000, 'k30000': 65536}.get(case, 64)
+    k = {'ties': 5, 'all_equal': 7, 'k_equals_n': 64, 'negatives_and_inf': 6, 'large': 409, 'n16000': 1600, 'n40000': 4000, 'k20000': 20000, 'k30000': 30000}[case]
+    if case == 'k30000' and mode == 1:
+        from ethz_safe_learning_amd._capi import CemError
+        with pytest.raises(CemError):
+            hp.make_planner(pb := hp.make_problem(seed=42), hp.configs(pb, N=N, H=3, P=5, E=5, k=k, I=1, select_mode=1)[1])
+        return
     H = 3
     # mode 1: the one-workgroup select kernel; mode 2: the multi-workgroup chain; mode 3: the chain fused into one launch with grid
     # barriers (what populations of 24 000 and more take automatically)
