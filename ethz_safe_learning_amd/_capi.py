@@ -42,7 +42,7 @@ class CemScorer(C.Structure):
 class CemConfig(C.Structure):
     _fields_ = [
         ('abi_version', C.c_int32), ('obs_dim', C.c_int32), ('act_dim', C.c_int32),
-        ('units', C.c_int32), ('n_layers', C.c_int32), ('ensemble_size', C.c_int32),
+        ('units', C.c_int32), ('n_layers', C.c_int32), ('activation', C.c_int32), ('ensemble_size', C.c_int32),
         ('particles', C.c_int32), ('n_samples', C.c_int32), ('horizon', C.c_int32),
         ('n_elite', C.c_int32), ('iterations', C.c_int32),
         ('smoothing', C.c_float), ('one_minus_smoothing', C.c_float), ('stddev_threshold', C.c_float), ('noise_stddev', C.c_float),
@@ -58,7 +58,7 @@ class CemConfig(C.Structure):
 
 class CemTrainConfig(C.Structure):
     _fields_ = [('abi_version', C.c_int32), ('inputs_dim', C.c_int32), ('outputs_dim', C.c_int32), ('units', C.c_int32),
-                ('n_layers', C.c_int32), ('ensemble_size', C.c_int32), ('batch_size', C.c_int32),
+                ('n_layers', C.c_int32), ('ensemble_size', C.c_int32), ('batch_size', C.c_int32), ('activation', C.c_int32),
                 ('beta1', C.c_float), ('beta2', C.c_float), ('epsilon', C.c_float), ('clipvalue', C.c_float)]
 
 

@@ -42,6 +42,7 @@ int validate(const cem_config_t *c)
         c->n_elite < 1 || c->n_elite > c->n_samples || c->world_size < 1 || c->rank < 0 || c->rank >= c->world_size)
         return CEM_ERR_INVALID_ARG;
     if (c->units < 1) return CEM_ERR_INVALID_ARG;
+    if (c->activation < CEM_ACT_RELU || c->activation > CEM_ACT_SOFTPLUS) return CEM_ERR_INVALID_ARG;
     if (!(fabs((double)c->one_minus_smoothing - (1.0 - (double)c->smoothing)) <= 2e-7)) return CEM_ERR_INVALID_ARG;   // see cem_mpc.h
     if (c->units > CEM_WIDE_U) return CEM_ERR_UNSUPPORTED;  // <= 128: the fast kernel (narrower layers run zero-padded, exactly); 129..256: cem_rollout_wide.h
     if (c->obs_dim + c->act_dim > CEM_U) return CEM_ERR_UNSUPPORTED;
@@ -87,7 +88,7 @@ Dims make_dims(const cem_config_t *c)
     d.Nloc = d.N / d.W; d.n_off = d.R * d.Nloc; d.Bloc = d.P * d.Nloc; d.Btot = d.P * d.N;
     d.KB_in = (d.Din + 15) / 16; d.KB_obs = (d.O + 15) / 16; d.NFW = (d.KB_in + 3) / 4; d.KF0 = 4 * d.NFW;
     d.act_q0 = d.O / 4; d.act_nq = (d.Din + 3) / 4 - d.act_q0;
-    d.wide = d.U > CEM_U;
+    d.wide = d.U > CEM_U || c->activation != CEM_ACT_RELU;   // the tuned kernels: units <= 128 and relu; everything else takes the generic rollout kernel
     uint32_t off = 0;
     for (int w = 0; w < 4; ++w) {
         int g = d.KF0 + CEM_NG * (d.L - 1);
@@ -824,7 +825,7 @@ hipError_t launch_rollout(int rc, int nfw, const RolloutParams &p, int n_tiles, 
 hipError_t launch_rollout_wide(const cem_planner *h, const RolloutParams &rp, int n_tiles)
 {
     WideParams wp; wp.r = rp;
-    wp.wnat = (const float *)(h->ws + h->lay.wpack); wp.nat = (uint32_t)h->d.nat_member_floats; wp.U = h->d.U;
+    wp.wnat = (const float *)(h->ws + h->lay.wpack); wp.nat = (uint32_t)h->d.nat_member_floats; wp.U = h->d.U; wp.act = h->cfg.activation;
     wp.wimg = (const f4 *)(h->ws + h->lay.wpack + align256((size_t)h->d.E * h->d.nat_member_floats * 4)); wp.img_f4 = (uint32_t)(wide_image_floats(h->d) / 4);
     hipLaunchKernelGGL(cem_rollout_wide_kernel, dim3(n_tiles), dim3(256), CEM_WIDE_SMEM, h->stream, wp);
     return hipGetLastError();
@@ -1343,7 +1344,7 @@ int validate_train(const cem_train_config_t *c)
 {
     if (!c || c->abi_version != CEM_ABI_VERSION) return CEM_ERR_INVALID_ARG;
     if (c->inputs_dim < 1 || c->outputs_dim < 1 || c->n_layers < 1 || c->ensemble_size < 1 || c->batch_size < 1) return CEM_ERR_INVALID_ARG;
-    if (c->units < 1) return CEM_ERR_INVALID_ARG;
+    if (c->units < 1 || c->activation < CEM_ACT_RELU || c->activation > CEM_ACT_SOFTPLUS) return CEM_ERR_INVALID_ARG;
     if (c->units > CEM_TWIDE || c->inputs_dim > CEM_U || c->outputs_dim > CEM_U || c->batch_size > CEM_TB) return CEM_ERR_UNSUPPORTED;
     return CEM_OK;
 }
@@ -1395,7 +1396,7 @@ void fill_train_params(const cem_trainer *t, TrainParams &p)
     p.nat = (uint32_t)t->nat; p.scratch_per_member = (uint32_t)t->scratch_pm;
     p.gpart = (uint32_t)((t->nat * c.ensemble_size + 3) & ~(size_t)3);
     p.ts = c.units > CEM_TS ? CEM_TWIDE : CEM_TS;
-    p.beta1 = c.beta1; p.beta2 = c.beta2; p.eps = c.epsilon; p.clip = c.clipvalue;
+    p.beta1 = c.beta1; p.beta2 = c.beta2; p.eps = c.epsilon; p.clip = c.clipvalue; p.act = c.activation;
     p.stamps = (long long *)(t->ws + t->oT);
 }
 }  // namespace
@@ -1427,7 +1428,8 @@ int cem_trainer_create(const cem_train_config_t *cfg, void *workspace, size_t wo
     }
     {   // the tile kernel keeps every layer's activations in LDS: (n_layers + 5) x 8 KB, beyond 48 KB only with the runtime's leave
         const size_t lds = (size_t)(cfg->n_layers + 5) * CEM_TT_NB * CEM_TT_BLK;
-        t->tile_kernel = cfg->n_layers <= CEM_TT_MAXL && cfg->units <= CEM_U && std::getenv("CEM_TRAIN_GEMM_KERNEL") == nullptr;   // the tile kernel is 8 blocks wide
+        t->tile_kernel = cfg->n_layers <= CEM_TT_MAXL && cfg->units <= CEM_U && cfg->activation == CEM_ACT_RELU &&
+                         std::getenv("CEM_TRAIN_GEMM_KERNEL") == nullptr;   // the tile kernel is 8 blocks wide and relu only
         hipError_t e = hipSuccess;
         if (t->tile_kernel) switch (cfg->n_layers) {
 #define CEM_CASE(LL) case LL: e = tile_kernel_lds<LL>(lds); break;

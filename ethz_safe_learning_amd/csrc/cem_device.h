@@ -223,6 +223,34 @@ __device__ __forceinline__ float cem_softplus(float x)
     return __builtin_fmaf(z, q, fmaxf(x, 0.f));
 }
 
+// mlp_params['activation'] (mlp_ensemble.py:14,20; enum cem_activation of cem_mpc.h): the hidden layers' nonlinearity on the generic
+// paths (cem_rollout_wide_kernel, cem_train_step_kernel) — the tuned kernels are relu only.  tanh / exp / expm1 are the device
+// library's (1-2 ulp).  The derivative is written as a function of the layer's OUTPUT h = f(z), which is what the backward pass
+// holds (TensorFlow's own EluGrad / SoftplusGrad / ReluGrad use the same forms): relu [h > 0], tanh 1 - h^2, sigmoid h (1 - h),
+// elu h + 1 below zero, leaky_relu 0.2 at and below zero, softplus sigma(z) = 1 - exp(-h).
+__device__ __forceinline__ float cem_activation_fwd(const int a, const float v)
+{
+    switch (a) {
+    case 1: return tanhf(v);
+    case 2: return 1.0f / (1.0f + expf(-v));
+    case 3: return v > 0.f ? v : expm1f(v);
+    case 4: return v > 0.f ? v : 0.2f * v;
+    case 5: return cem_softplus(v);
+    default: return fmaxf(v, 0.f);
+    }
+}
+__device__ __forceinline__ float cem_activation_gate(const int a, const float d, const float h)     // d * f'(z), given h = f(z)
+{
+    switch (a) {
+    case 1: return d * (1.0f - h * h);
+    case 2: return d * (h * (1.0f - h));
+    case 3: return h < 0.f ? d * (h + 1.0f) : d;
+    case 4: return h > 0.f ? d : 0.2f * d;
+    case 5: return d * (1.0f - expf(-h));
+    default: return h > 0.f ? d : 0.f;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // rollout kernel
 // ---------------------------------------------------------------------------------------------------------

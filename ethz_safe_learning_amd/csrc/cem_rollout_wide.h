@@ -25,6 +25,7 @@ struct WideParams {
     uint32_t nat;                            // floats per member
     uint32_t img_f4;                         // f4 per member image
     int32_t U;
+    int32_t act;                             // enum cem_activation of the hidden layers
 };
 
 // Packed image of one member (host: pack_member_wide; device: here).  Group of (layer l, k block kb, output block ob):
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void cem_rollout_wide_kernel(const WideParams 
                     if (ob < nbU) {                                                   // wave-uniform
                         f4 h = acc[i];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) h[r] = (16 * ob + 4 * q + r < U) ? fmaxf(h[r], 0.f) : 0.f;
+                        for (int r = 0; r < 4; ++r) h[r] = (16 * ob + 4 * q + r < U) ? (wp.act == 0 ? fmaxf(h[r], 0.f) : cem_activation_fwd(wp.act, h[r])) : 0.f;
                         *reinterpret_cast<f4 *>(smem + xw + (ob * 64 + lane) * 16) = h;
                     }
                 }

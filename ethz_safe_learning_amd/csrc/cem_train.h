@@ -38,6 +38,7 @@ struct TrainParams {
     float lr_t, beta1, beta2, eps, clip;
     float *loss_out;             // train: [E] loss share of each member; eval: [E][2] raw sums (log term, squared term)
     int32_t train;
+    int32_t act;                 // enum cem_activation of the hidden layers (the tile kernel is relu only: cem_capi.hip routes the others here)
     long long *stamps;           // [32] phase stamps (member 0), written by -DCEM_STAMPS diagnostic builds only
 };
 
@@ -74,8 +75,8 @@ typedef __attribute__((address_space(1))) float *gptr;              // function 
 struct GemmEpi {
     gptr out; int ldo;
     gcptr bias;            // [N] or null
-    gcptr gate; int ldg;   // [M][ldg] or null
-    int relu;
+    gcptr gate; int ldg;   // [M][ldg] or null: v = v * f'(z) with gate = f(z), the gated layer's output
+    int relu;              // 0: none; 1 + enum cem_activation: the hidden layers' nonlinearity (forward) / the one whose derivative gates (backward)
     // optional column split (the mu | variance head pair as ONE GEMM): columns n >= nsplit go to out1 / bias1 at n - nsplit
     gptr out1; gcptr bias1;
     long long *st;         // -DCEM_STAMPS builds: accumulates [8] prologue (first slab in LDS), [9] k loop, [10] epilogue cycles of member 0
@@ -227,8 +228,8 @@ __device__ __attribute__((noinline)) void wg_gemm_t(const int M, const int N, co
                         const int mI = m0 + 16 * rb + 64 * rk + 4 * kq + i, n = n0 + CW * ch + 16 * jn + li;
                         float v = acc[rk][jn][i];
                         if (e.bias) v = v + bia[jn];
-                        if (e.relu) v = fmaxf(v, 0.f);
-                        if (e.gate) v = gat[rk][i][jn] > 0.f ? v : 0.f;
+                        if (e.gate) v = e.relu <= 1 ? (gat[rk][i][jn] > 0.f ? v : 0.f) : cem_activation_gate(e.relu - 1, v, gat[rk][i][jn]);
+                        else if (e.relu) v = e.relu == 1 ? fmaxf(v, 0.f) : cem_activation_fwd(e.relu - 1, v);
                         if (mI < M && n < N) (n < sp.nsplit ? e.out : e.out1)[(mI < M ? mI : M - 1) * e.ldo + (n < sp.nsplit ? n : n - sp.nsplit)] = v;
                     }
 #ifdef CEM_STAMPS
@@ -350,8 +351,8 @@ __device__ __attribute__((noinline)) void wg_gemm_r16_deep(const int M, const in
         const int mI = 4 * kq + i;
         float v = acc[i];
         if (e.bias) v = v + bia;
-        if (e.relu) v = fmaxf(v, 0.f);
-        if (e.gate) v = gat[i] > 0.f ? v : 0.f;
+        if (e.gate) v = e.relu <= 1 ? (gat[i] > 0.f ? v : 0.f) : cem_activation_gate(e.relu - 1, v, gat[i]);
+        else if (e.relu) v = e.relu == 1 ? fmaxf(v, 0.f) : cem_activation_fwd(e.relu - 1, v);
         if (mI < M && n < N) (n < sp.nsplit ? e.out : e.out1)[mI * e.ldo + (n < sp.nsplit ? n : n - sp.nsplit)] = v;
     }
 #ifdef CEM_STAMPS
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
         const float *hin = l == 0 ? xs : hs + (size_t)(l - 1) * CEM_TROWS * S;
         float *hout = hs + (size_t)l * CEM_TROWS * S;
         const float *Wl = W + offW(l), *bl = W + offb(l);
-        wg_gemm(Bt, U, l == 0 ? D : U, (gcptr)hin, S, 1, (gcptr)Wl, U, 1, GemmEpi{(gptr)hout, S, (gcptr)bl, nullptr, 0, 1, nullptr, nullptr, p.stamps, nullptr, nullptr}, CEM_NOSPLIT);     // relu(h W + b)
+        wg_gemm(Bt, U, l == 0 ? D : U, (gcptr)hin, S, 1, (gcptr)Wl, U, 1, GemmEpi{(gptr)hout, S, (gcptr)bl, nullptr, 0, 1 + p.act, nullptr, nullptr, p.stamps, nullptr, nullptr}, CEM_NOSPLIT);     // f(h W + b), f = relu unless configured otherwise
     }
     CEM_TR_STAMP(2);
     const float *hL = hs + (size_t)(L - 1) * CEM_TROWS * S;
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
     // dh_L = (dmu Wmu^T + dv Wvar^T) * relu'(h_L): the relu mask rides in the epilogue of the GEMM that completes dh
     // dh_L = ([dmu | dv] [W_mu | W_var]^T) * relu'(h_L): one GEMM over K = 2O; the relu mask rides in its epilogue
     wg_gemm(Bt, U, 2 * O, (gcptr)dmu, S, 1, (gcptr)(W + oWmu), 1, O,
-            GemmEpi{(gptr)dha, S, nullptr, (gcptr)hL, S, 0, nullptr, nullptr, p.stamps, nullptr, nullptr}, GemmSplit{(gcptr)dv, (gcptr)(W + oWv), O, 0x7fffffff});
+            GemmEpi{(gptr)dha, S, nullptr, (gcptr)hL, S, 1 + p.act, nullptr, nullptr, p.stamps, nullptr, nullptr}, GemmSplit{(gcptr)dv, (gcptr)(W + oWv), O, 0x7fffffff});
     CEM_TR_STAMP(6);
     float *dcur = dha, *dnext = dhb;
     for (int l = L - 1; l >= 0; --l) {
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
         const int in = l == 0 ? D : U;
         wg_gemm(in, U, Bt, (gcptr)hin, 1, S, (gcptr)dcur, S, 1, GemmEpi{(gptr)(G + offW(l)), U, nullptr, nullptr, 0, 0, nullptr, nullptr, p.stamps, (gptr)(G + offb(l)), nullptr}, CEM_NOSPLIT);   // dW_l = h_{l-1}^T dh_l, db_l = column sums of dh_l
         if (l > 0) {
-            wg_gemm(Bt, U, U, (gcptr)dcur, S, 1, (gcptr)(W + offW(l)), 1, U, GemmEpi{(gptr)dnext, S, nullptr, (gcptr)hin, S, 0, nullptr, nullptr, p.stamps, nullptr, nullptr}, CEM_NOSPLIT);   // dh_{l-1} = (dh_l W_l^T) relu'
+            wg_gemm(Bt, U, U, (gcptr)dcur, S, 1, (gcptr)(W + offW(l)), 1, U, GemmEpi{(gptr)dnext, S, nullptr, (gcptr)hin, S, 1 + p.act, nullptr, nullptr, p.stamps, nullptr, nullptr}, CEM_NOSPLIT);   // dh_{l-1} = (dh_l W_l^T) relu'
             float *t = dcur; dcur = dnext; dnext = t;
         }
     }

@@ -48,6 +48,7 @@ class PlannerConfig:
     act_high: Sequence[float]
     units: int = 128
     n_layers: int = 4
+    activation: str = 'relu'           # mlp_params['activation'] (config/models.yaml:12): relu | tanh | sigmoid | elu | leaky_relu | softplus (see ACTIVATIONS)
     smoothing: float = 0.0
     stddev_threshold: float = -1.0
     noise_stddev: float = 0.0
@@ -61,6 +62,20 @@ class PlannerConfig:
     use_graph: bool = False
     rollout_segments: int = 0          # 0 auto, 1 off, n > 1: horizon-segment work queue (cem_mpc.h)
     select_mode: int = 0               # 0 auto, 1 one-workgroup select, 2 multi-workgroup chain, 3 the chain fused into one launch (cem_mpc.h)
+
+
+# mlp_params['activation'] is a string the reference `eval`s (mlp_ensemble.py:14): the TensorFlow names that map onto enum cem_activation
+ACTIVATIONS = {'relu': 0, 'tanh': 1, 'sigmoid': 2, 'elu': 3, 'leaky_relu': 4, 'softplus': 5}
+
+
+def activation_code(name) -> int:
+    """'tf.nn.relu' / 'tf.nn.tanh' / 'tf.math.tanh' / 'tf.keras.activations.elu' / 'relu' ... -> enum cem_activation.  Raises
+    for anything else (swish / gelu / selu need the pre-activation in the backward pass, which the device trainer does not keep)."""
+    key = str(name).strip().split('.')[-1].lower()
+    if key not in ACTIVATIONS:
+        raise NotImplementedError("activation %r is not built (supported: %s — as bare names or with a tf.nn. / tf.math. / "
+                                  "tf.keras.activations. prefix)" % (name, ', '.join(sorted(ACTIVATIONS))))
+    return ACTIVATIONS[key]
 
 
 def sampling_params(low, high):
@@ -78,6 +93,7 @@ def to_c_config(cfg: PlannerConfig) -> _capi.CemConfig:
     c = _capi.CemConfig()
     c.abi_version = _capi.CEM_ABI_VERSION
     c.obs_dim, c.act_dim, c.units, c.n_layers = cfg.obs_dim, cfg.act_dim, cfg.units, cfg.n_layers
+    c.activation = activation_code(cfg.activation)
     c.ensemble_size, c.particles, c.n_samples = cfg.ensemble_size, cfg.particles, cfg.n_samples
     c.horizon, c.n_elite, c.iterations = cfg.horizon, cfg.n_elite, cfg.iterations
     c.smoothing, c.stddev_threshold, c.noise_stddev = cfg.smoothing, cfg.stddev_threshold, cfg.noise_stddev

@@ -24,9 +24,9 @@ class MlpEnsemble(object):
         self.training_steps = training_steps
         self.train_epochs = train_epochs
         self.mlp_params = dict(mlp_params or dict(n_layers=4, units=128, activation='tf.nn.relu', dropout_rate=0.0))
-        act = self.mlp_params.get('activation', 'tf.nn.relu')
-        if act not in ('tf.nn.relu', 'relu'):
-            raise NotImplementedError('only the relu activation of config/models.yaml:12 is built into the kernel')
+        from ...planner import activation_code
+        self.activation = self.mlp_params.get('activation', 'tf.nn.relu')       # the reference evals this string (mlp_ensemble.py:14)
+        activation_code(self.activation)                                         # raises NotImplementedError for what is not built
         if float(self.mlp_params.get('dropout_rate', 0.0)) != 0.0:
             raise NotImplementedError('dropout_rate != 0 is not built: the device trainer (cem_train_tile.h) has no dropout mask; '
                                       'config/models.yaml ships 0.0, where the reference\'s Dropout layer is the identity (mlp_ensemble.py:21)')
@@ -77,7 +77,7 @@ class MlpEnsemble(object):
         from ...trainer import CemTrainer
         if getattr(self, '_trainer', None) is None:
             self._trainer = CemTrainer(self.inputs_dim, self.outputs_dim, self.mlp_params['units'], self.mlp_params['n_layers'],
-                                       self.ensemble_size, batch_size=self.batch_size, device=device)
+                                       self.ensemble_size, batch_size=self.batch_size, device=device, activation=self.activation)
             self._trainer_version = None
         if self._trainer_version != self.version:           # weights were replaced from outside: Adam moments restart
             self._trainer.set_state(self._weights)

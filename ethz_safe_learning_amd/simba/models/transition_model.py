@@ -75,7 +75,7 @@ class TransitionModel(BaseModel):
                                 ensemble_size=ens.ensemble_size, particles=ens.ensemble_size, n_samples=16, horizon=1,
                                 n_elite=1, iterations=1, scorer=ScorerConfig(goal_slice=(0, 1)),
                                 act_low=self.action_space.low, act_high=self.action_space.high,
-                                units=ens.mlp_params['units'], n_layers=ens.mlp_params['n_layers'],
+                                units=ens.mlp_params['units'], n_layers=ens.mlp_params['n_layers'], activation=ens.activation,
                                 sampling_propagation=self.sampling_propagation, scale_features=self.scale_features)
             self._planner = CemPlanner(cfg, device=device)
         if self._planner_version != self.version:

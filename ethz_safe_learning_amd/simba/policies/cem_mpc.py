@@ -47,7 +47,7 @@ class CemMpc(MpcPolicy):
             obs_dim=m.observation_space_dim, act_dim=m.action_space_dim, ensemble_size=ens.ensemble_size,
             particles=self.particles, n_samples=self.n_samples, horizon=self.horizon, n_elite=self.elite,
             iterations=self.iterations, scorer=self._scorer_config(), act_low=self.action_space.low,
-            act_high=self.action_space.high, units=ens.mlp_params['units'], n_layers=ens.mlp_params['n_layers'],
+            act_high=self.action_space.high, units=ens.mlp_params['units'], n_layers=ens.mlp_params['n_layers'], activation=ens.activation,
             smoothing=self.smoothing, stddev_threshold=self.stddev_threshold, noise_stddev=self.noise_stddev,
             variant=self.variant, sampling_propagation=m.sampling_propagation, scale_features=m.scale_features,
             use_graph=self.use_graph, **self._extra_config())

@@ -45,7 +45,7 @@ class MpcPolicy(PolicyBase):
         cfg = PlannerConfig(obs_dim=m.observation_space_dim, act_dim=m.action_space_dim, ensemble_size=ens.ensemble_size,
                             particles=self.particles, n_samples=ens.ensemble_size, horizon=1, n_elite=1, iterations=1,
                             scorer=scorer.to_scorer_config(), act_low=self.action_space.low, act_high=self.action_space.high,
-                            units=ens.mlp_params['units'], n_layers=ens.mlp_params['n_layers'], variant=self.variant,
+                            units=ens.mlp_params['units'], n_layers=ens.mlp_params['n_layers'], activation=ens.activation, variant=self.variant,
                             **self._objective_extra_config())
         return cached_planner(cfg, device=getattr(self, 'device', 'cuda:0'))
 

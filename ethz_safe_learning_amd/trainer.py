@@ -35,7 +35,7 @@ class CemTrainer:
     reference mlp_ensemble.py:113-117)."""
 
     def __init__(self, inputs_dim, outputs_dim, units, n_layers, ensemble_size, batch_size=64, beta1=0.9, beta2=0.999,
-                 epsilon=1e-5, clipvalue=1.0, device='cuda:0'):
+                 epsilon=1e-5, clipvalue=1.0, device='cuda:0', activation='relu'):
         import torch
         self._torch = torch
         self.lib = _capi.load()
@@ -47,6 +47,8 @@ class CemTrainer:
         c.abi_version = _capi.CEM_ABI_VERSION
         c.inputs_dim, c.outputs_dim, c.units, c.n_layers, c.ensemble_size = inputs_dim, outputs_dim, units, n_layers, ensemble_size
         c.batch_size, c.beta1, c.beta2, c.epsilon, c.clipvalue = batch_size, beta1, beta2, epsilon, clipvalue
+        from .planner import activation_code
+        c.activation = activation_code(activation)
         self.ccfg = c
         self.device = torch.device(device)
         nbytes = self.lib.cem_trainer_workspace_bytes(C.byref(c))

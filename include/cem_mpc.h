@@ -49,6 +49,11 @@ enum cem_status {
 
 enum cem_variant { CEM_VARIANT_CEM = 0 /* CemMpc */, CEM_VARIANT_SAFE = 1 /* SafeCemMpc */ };
 
+/* mlp_params['activation'] of config/models.yaml:12, which the reference `eval`s (mlp_ensemble.py:14): the hidden layers'
+ * nonlinearity.  relu (the shipped value) runs on the tuned kernels; the others on the width-generic rollout kernel and the
+ * GEMM-by-GEMM trainer (functional paths).  tf.nn.elu: alpha 1; tf.nn.leaky_relu: alpha 0.2 (TensorFlow's defaults). */
+enum cem_activation { CEM_ACT_RELU = 0, CEM_ACT_TANH = 1, CEM_ACT_SIGMOID = 2, CEM_ACT_ELU = 3, CEM_ACT_LEAKY_RELU = 4, CEM_ACT_SOFTPLUS = 5 };
+
 /* SafetyGymStateScorer fields used by the 'goal' task (safety_gym.py:104-176).
  * The constants come from safety_gym's Engine config (absent from the
  * reference tree), hence explicit. */
@@ -79,6 +84,7 @@ typedef struct cem_config {
     int32_t units, n_layers;      /* mlp_params: units <= 128 run on the fast kernels (narrower layers zero-padded to the 128-wide form:
                                    * exactly the narrow network's result); 129..256 on width-generic kernels (same semantics, the natural
                                    * weight blob read in place; a functional path, not a tuned one) */
+    int32_t activation;           /* enum cem_activation */
     int32_t ensemble_size;        /* E */
     int32_t particles;            /* P */
     int32_t n_samples;            /* N (global, over all ranks) */
@@ -245,6 +251,7 @@ typedef struct cem_train_config {
     int32_t abi_version;
     int32_t inputs_dim, outputs_dim, units, n_layers, ensemble_size;
     int32_t batch_size;           /* rows per member per step, <= 64 (config/models.yaml:4) */
+    int32_t activation;           /* enum cem_activation */
     float beta1, beta2, epsilon, clipvalue;
 } cem_train_config_t;
 typedef struct cem_trainer cem_trainer_t;

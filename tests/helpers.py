@@ -32,6 +32,7 @@ def configs(pb, N, H, P, E, k, I=3, variant='cem', thr=-1.0, noise=0.0, post=0.3
                                              reward_clip=sp.reward_clip, constrain_indicator=sp.constrain_indicator,
                                              cost_kinds=list(sp.cost_kinds)),
                          act_low=pb['low'], act_high=pb['high'], n_layers=len(pb['weights'][0]['W']), units=pb['weights'][0]['W'][0].shape[1],
+                         activation=pb['weights'][0].get('activation', 'relu'),
                          smoothing=smoothing,
                          stddev_threshold=thr, noise_stddev=noise, variant=variant, posterior_mean_threashold=post,
                          sampling_propagation=sampling, scale_features=scale, world_size=world_size, rank=rank,

@@ -947,6 +947,37 @@ def test_select_modes_agree_on_a_whole_plan():
     np.testing.assert_array_equal(res[1][4], res[2][4])
 
 
+@pytest.mark.parametrize('units', [128, 40])
+@pytest.mark.parametrize('activation', ['tf.nn.tanh', 'tf.nn.sigmoid', 'tf.nn.elu', 'tf.nn.leaky_relu', 'tf.nn.softplus'])
+def test_other_activations_match_oracle(activation, units):
+    """mlp_params['activation'] other than relu (config/models.yaml:12 takes any TensorFlow activation; the reference evals the
+    string, mlp_ensemble.py:14,20): the generic rollout kernel applies it in the hidden layers — per-candidate scores against the
+    fp64 oracle (near-threshold candidates included) and a whole plan against the fp32 oracle on identical noise."""
+    torch = _torch()
+    pb = hp.make_problem(60, 2, 5, 3, seed=61, units=units, activation=activation)
+    N, H, P, E, I = 64, 7, 5, 5, 3
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=6, I=I, variant='safe', post=0.5, noise=0.01)
+    assert pcfg.activation == activation
+    pl = hp.make_planner(pb, pcfg)
+    ea, em, eo = hp.noise(I, N, H, 2, P, 60, seed=8)
+    actions, returns, scores = _run_iteration(pl, pb, ocfg, ea, em)
+    pl.plan_end()
+    ref64, traj64 = o.candidate_scores(pb['state'].astype(np.float64), actions.astype(np.float64), o.cast_weights(pb['weights'], np.float64),
+                                       pb['inputs_min'], pb['inputs_max'], em[0], ocfg, pb['scorer'], return_traj=True)
+    err, n_near, _ = hp.assert_scores_match_oracle(scores, traj64, P, N, pb['scorer'], 'safe', 0.5, ATOL, '%s units %d' % (activation, units))
+    # the activation really is in the network: the relu oracle gives different scores
+    relu_w = [{k: v for k, v in w.items() if k != 'activation'} for w in o.cast_weights(pb['weights'], np.float64)]
+    ref_relu = o.candidate_scores(pb['state'].astype(np.float64), actions.astype(np.float64), relu_w, pb['inputs_min'], pb['inputs_max'],
+                                  em[0], ocfg, pb['scorer'])
+    assert np.abs(ref_relu - ref64).max() > 1e-3
+    a, s, it = pl.plan(pb['state'], eps_act=ea, eps_model=em, eps_out=eo)
+    ra, rs, rit = o.do_generate_action(pb['state'], pb['weights'], pb['inputs_min'], pb['inputs_max'], pb['low'], pb['high'],
+                                       ea, em, eo, ocfg, pb['scorer'])
+    assert it == rit and abs(s - rs) <= 2e-5
+    np.testing.assert_allclose(a, ra, rtol=1e-5, atol=1e-6)
+    print('%s units %d: max|gpu-f64| = %.3g (%d near a threshold)' % (activation, units, err, n_near))
+
+
 @pytest.mark.parametrize('units', [64, 100, 17])
 def test_narrow_hidden_layers_run_zero_padded(units):
     """`units` below 128 (config/models.yaml:11 takes any value): the library pads the layers to its 128-wide kernel with zero

@@ -12,8 +12,8 @@ from tests import helpers as hp
 pytestmark = pytest.mark.gpu
 
 
-def _setup(E=3, D=62, O=60, L=4, seed=0, units=128):
-    pb = hp.make_problem(O, D - O, E, L, seed=seed, bias_noise=0.05, head_scale=0.3, var_bias=-2.0, units=units)
+def _setup(E=3, D=62, O=60, L=4, seed=0, units=128, activation='relu'):
+    pb = hp.make_problem(O, D - O, E, L, seed=seed, bias_noise=0.05, head_scale=0.3, var_bias=-2.0, units=units, activation=activation)
     rng = np.random.default_rng(seed)
     n = 500
     X = rng.normal(0, 0.5, (n, D)).astype(np.float32)
@@ -171,3 +171,42 @@ def test_validation_loss_over_many_chunks(kernel, monkeypatch):
         want = ref if rows == n else o.validation_loss(o.cast_weights(pb['weights'], np.float64), X[:rows].astype(np.float64), Y[:rows].astype(np.float64))
         assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (rows, got, want)
     tr.close()
+
+
+@pytest.mark.parametrize('activation', ['tf.nn.tanh', 'tf.nn.sigmoid', 'tf.nn.elu', 'tf.nn.leaky_relu', 'tf.nn.softplus'])
+@pytest.mark.parametrize('E,D,O,L,bt,units', [(2, 62, 60, 3, 64, 128), (2, 20, 17, 2, 37, 48)])
+def test_training_steps_with_other_activations(E, D, O, L, bt, units, activation):
+    """mlp_params['activation'] other than relu (the reference evals any string, mlp_ensemble.py:14): the GEMM-by-GEMM trainer with
+    the activation in its forward epilogues and f'(z) — as a function of the layer's output — in the backward gates, against the
+    oracle's manual backward pass, which takes f' from the PRE-activation."""
+    import torch
+    from ethz_safe_learning_amd.trainer import CemTrainer
+    pb, X, Y, rng = _setup(E, D, O, L, seed=E + 10, units=units, activation=activation)
+    tr = CemTrainer(D, O, units, L, E, batch_size=64, activation=activation)
+    tr.set_state(pb['weights'])
+    w64 = o.cast_weights(pb['weights'], np.float64)
+    assert w64[0]['activation'] == activation
+    ms64, vs64 = o.zeros_like_weights(w64), o.zeros_like_weights(w64)
+    x_dev, y_dev = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()
+    lr = 0.00025
+    for t in range(1, 4):
+        perm = np.stack([rng.permutation(X.shape[0]) for _ in range(E)]).astype(np.int32)
+        loss_dev = torch.zeros(E, device='cuda')
+        tr.step(x_dev, y_dev, torch.from_numpy(perm).cuda(), 5 * t, bt, lr, loss_dev)
+        tr.synchronize()
+        idx = perm[:, 5 * t:5 * t + bt]
+        ref = o.training_step(w64, ms64, vs64, X[idx].astype(np.float64), Y[idx].astype(np.float64), lr, t)
+        got = float(loss_dev.sum().item())
+        assert abs(got - ref) <= 1e-5 * max(1.0, abs(ref)), (activation, t, got, ref)
+    worst = 0.0
+    for a, b in zip(tr.get_weights(), w64):
+        for ka, kb in zip(o._flat_params(a), o._flat_params(b)):
+            worst = max(worst, float(np.abs(ka - kb).max()))
+    print('%s: max |w_gpu - w_f64| after 3 Adam steps: %.3g' % (activation, worst))
+    assert worst <= 2e-5
+    vl = tr.validation_loss(x_dev[:100], y_dev[:100])
+    gw64 = o.cast_weights(tr.get_weights(), np.float64)
+    for m in gw64:
+        m['activation'] = activation
+    ref_vl = o.validation_loss(gw64, X[:100].astype(np.float64), Y[:100].astype(np.float64))
+    assert abs(vl - ref_vl) <= 1e-5 * max(1.0, abs(ref_vl))

@@ -19,6 +19,25 @@ def test_softplus_three_branches():
     assert abs(float(y[3]) - np.log1p(np.exp(-8.0))) < 1e-10
 
 
+def test_activations_follow_tensorflow_definitions():
+    """mlp_params['activation'] is eval'ed by the reference (mlp_ensemble.py:14): values and gradients of the TensorFlow functions
+    at hand-picked points, incl. the kinks (relu' (0) = 0, leaky_relu' (0) = alpha = 0.2, elu' (0) = 1)."""
+    z = np.array([-2.0, -0.5, 0.0, 0.5, 2.0])
+    want = {'tf.nn.relu': ([0, 0, 0, 0.5, 2.0], [0, 0, 0, 1, 1]),
+            'tf.nn.tanh': (np.tanh(z), 1 - np.tanh(z) ** 2),
+            'tf.nn.sigmoid': (1 / (1 + np.exp(-z)), np.exp(-z) / (1 + np.exp(-z)) ** 2),
+            'tf.nn.elu': ([np.exp(-2.0) - 1, np.exp(-0.5) - 1, 0, 0.5, 2.0], [np.exp(-2.0), np.exp(-0.5), 1, 1, 1]),
+            'tf.nn.leaky_relu': ([-0.4, -0.1, 0, 0.5, 2.0], [0.2, 0.2, 0.2, 1, 1]),
+            'tf.nn.softplus': (np.log1p(np.exp(z)), 1 / (1 + np.exp(-z)))}
+    for name, (fv, dv) in want.items():
+        f, df = o.activation_and_grad(name)
+        np.testing.assert_allclose(f(z), fv, rtol=1e-12, atol=1e-15, err_msg=name)
+        np.testing.assert_allclose(df(z), dv, rtol=1e-12, atol=1e-15, err_msg=name)
+        assert o.activation_and_grad(name.split('.')[-1])[0](z).tolist() == f(z).tolist()      # bare names too
+    with pytest.raises(NotImplementedError):
+        o.activation_and_grad('tf.nn.swish')
+
+
 def test_scale_rule():
     # transition_model.py:83-87: delta < 1e-5 -> 1.01
     x = np.array([[2.0, 5.0, 1.0]], np.float32)

@@ -5,8 +5,9 @@ import numpy as np
 from oracle import cem_oracle as o
 
 
-def _tiny(seed=0):
-    pb = o.synthetic_problem(obs_dim=5, act_dim=2, ensemble_size=2, units=8, n_layers=2, seed=seed, head_scale=0.5, var_bias=-1.0)
+def _tiny(seed=0, activation='relu'):
+    pb = o.synthetic_problem(obs_dim=5, act_dim=2, ensemble_size=2, units=8, n_layers=2, seed=seed, head_scale=0.5, var_bias=-1.0,
+                             activation=activation)
     rng = np.random.default_rng(seed)
     w = o.cast_weights(pb['weights'], np.float64)
     for m in w:
@@ -17,8 +18,12 @@ def _tiny(seed=0):
     return w, x, y
 
 
-def test_gradients_match_finite_differences():
-    w, x, y = _tiny()
+import pytest
+
+
+@pytest.mark.parametrize('activation', ['relu', 'tf.nn.tanh', 'tf.nn.sigmoid', 'tf.nn.elu', 'tf.nn.leaky_relu', 'tf.nn.softplus'])
+def test_gradients_match_finite_differences(activation):
+    w, x, y = _tiny(activation=activation)
     loss, g = o.member_loss_and_grads(w[0], x[0], y[0], 2)
     eps = 1e-6
     rng = np.random.default_rng(1)

@@ -21,12 +21,14 @@ MODELS_YAML = dict(ensemble_size=15, batch_size=64, validation_split=0.2, learni
                    training_steps=5000, mlp_params=dict(n_layers=4, units=128, activation='tf.nn.relu', dropout_rate=0.0))
 
 
-def make_agent_parts(policy_name, seed=0, units=None):
+def make_agent_parts(policy_name, seed=0, units=None, activation=None):
     """What MbrlAgent.__init__ does (mbrl_agent.py:27-35,103-118; agent_factory.py:22 injects train_epochs)."""
     env = SyntheticSafetyGym()
     model_params = dict(MODELS_YAML, scale_features=True, train_epochs=10, seed=seed)
     if units is not None:                                  # models.yaml:11 takes any width
         model_params['mlp_params'] = dict(MODELS_YAML['mlp_params'], units=units)
+    if activation is not None:                             # models.yaml:12: any string the reference can eval
+        model_params['mlp_params'] = dict(model_params['mlp_params'], activation=activation)
     model = TransitionModel(model='mlp_ensemble', observation_space=env.observation_space, action_space=env.action_space,
                             sampling_propagation=True, **model_params)
     policy_params = dict(POLICIES_YAML[policy_name])
@@ -237,3 +239,42 @@ def test_predict_draws_fresh_noise_per_call():
     a, b = model.predict(x), model.predict(x)
     assert not np.array_equal(a, b)
     np.testing.assert_array_equal(model.predict(x, seed=3, call=9), model.predict(x, seed=3, call=9))
+
+
+def test_unknown_activation_is_refused_with_a_reason():
+    with pytest.raises(NotImplementedError, match='swish'):
+        make_agent_parts('cem_mpc', activation='tf.nn.swish')
+
+
+@pytest.mark.gpu
+def test_model_with_another_activation_fits_and_plans():
+    """models.yaml `activation: tf.nn.elu` through the simba classes: MlpEnsemble.fit on the device (the GEMM trainer), then
+    SafeCemMpc.generate_action (the generic rollout kernel) against the oracle on the FITTED weights with that activation."""
+    env, model, pol = make_agent_parts('safe_cem_mpc', seed=5, activation='tf.nn.elu')
+    rng = np.random.default_rng(4)
+    obs = rng.normal(0, 0.5, (400, 60)).astype(np.float32)
+    acs = rng.uniform(-1, 1, (400, 2)).astype(np.float32)
+    nxt = (obs + 0.05 * np.tanh(obs) + 0.02 * rng.normal(0, 1, obs.shape)).astype(np.float32)
+    model.model.training_steps, model.model.train_epochs = 40, 1
+    w0 = model.model.get_weights()[0]['W'][0].copy()
+    model.fit(np.concatenate([obs, acs], axis=1), nxt)      # TransitionModel.fit(inputs = [obs | acs], targets = next_obs), transition_model.py:31-40
+    ws = model.model.get_weights()
+    assert np.abs(ws[0]['W'][0] - w0).max() > 1e-4, 'fit did not move the weights'
+    pp = POLICIES_YAML['safe_cem_mpc']
+    I, N, H, P = pp['iterations'], pp['n_samples'], pp['horizon'], pp['particles']
+    state = rng.normal(0, 0.3, 60)
+    for lo, hi in ((3, 19), (22, 38), (41, 57)):
+        state[lo:hi] = rng.uniform(0.3, 0.9, hi - lo)
+    ea = rng.standard_normal((I, N, H, 2)).astype(np.float32)
+    em = rng.standard_normal((I, H, P * N, 60)).astype(np.float32)
+    eo = rng.standard_normal(2).astype(np.float32)
+    a, s = pol.do_generate_action(state, eps_act=ea, eps_model=em, eps_out=eo)
+    for w in ws:
+        w['activation'] = 'tf.nn.elu'
+    ocfg = o.PlanConfig(horizon=H, iterations=I, n_samples=N, n_elite=pp['n_elite'], particles=P, ensemble_size=15,
+                        smoothing=pp['smoothing'], stddev_threshold=pp['stddev_threshold'], noise_stddev=pp['noise_stddev'],
+                        variant='safe', posterior_mean_threashold=pp.get('posterior_mean_threashold', 0.15))
+    ra, rs, rit = o.do_generate_action(state.astype(np.float32), ws, model.inputs_min, model.inputs_max, env.action_space.low,
+                                       env.action_space.high, ea, em, eo, ocfg, o.ScorerParams(goal_slice=(3, 19), cost_kinds=[(22, 38, 0.2)]))
+    assert pol.last_iterations == rit and abs(s - rs) <= 2e-5
+    np.testing.assert_allclose(a, ra, rtol=1e-5, atol=1e-6)
