@@ -59,6 +59,7 @@ class CemConfig(C.Structure):
 class CemTrainConfig(C.Structure):
     _fields_ = [('abi_version', C.c_int32), ('inputs_dim', C.c_int32), ('outputs_dim', C.c_int32), ('units', C.c_int32),
                 ('n_layers', C.c_int32), ('ensemble_size', C.c_int32), ('batch_size', C.c_int32), ('activation', C.c_int32),
+                ('dropout_rate', C.c_float), ('dropout_seed_lo', C.c_uint32), ('dropout_seed_hi', C.c_uint32),
                 ('beta1', C.c_float), ('beta2', C.c_float), ('epsilon', C.c_float), ('clipvalue', C.c_float)]
 
 

@@ -1336,6 +1336,7 @@ struct cem_trainer {
     size_t nat, scratch_pm;
     size_t oW, oM, oV, oG, oS, oL, oP, oT, total;
     bool tile_kernel;
+    uint32_t steps_done;                     // training steps since create / set_state: the step index of the Dropout masks
     float *eval_part; size_t eval_part_floats;     // per-chunk loss partials of a one-launch validation pass (grown on demand, kept)
 };
 
@@ -1345,6 +1346,7 @@ int validate_train(const cem_train_config_t *c)
     if (!c || c->abi_version != CEM_ABI_VERSION) return CEM_ERR_INVALID_ARG;
     if (c->inputs_dim < 1 || c->outputs_dim < 1 || c->n_layers < 1 || c->ensemble_size < 1 || c->batch_size < 1) return CEM_ERR_INVALID_ARG;
     if (c->units < 1 || c->activation < CEM_ACT_RELU || c->activation > CEM_ACT_SOFTPLUS) return CEM_ERR_INVALID_ARG;
+    if (!(c->dropout_rate >= 0.f && c->dropout_rate < 1.f)) return CEM_ERR_INVALID_ARG;
     if (c->units > CEM_TWIDE || c->inputs_dim > CEM_U || c->outputs_dim > CEM_U || c->batch_size > CEM_TB) return CEM_ERR_UNSUPPORTED;
     return CEM_OK;
 }
@@ -1397,6 +1399,11 @@ void fill_train_params(const cem_trainer *t, TrainParams &p)
     p.gpart = (uint32_t)((t->nat * c.ensemble_size + 3) & ~(size_t)3);
     p.ts = c.units > CEM_TS ? CEM_TWIDE : CEM_TS;
     p.beta1 = c.beta1; p.beta2 = c.beta2; p.eps = c.epsilon; p.clip = c.clipvalue; p.act = c.activation;
+    if (c.dropout_rate > 0.f) {
+        p.drop_thresh = (uint32_t)std::min(4294967295.0, std::floor((double)c.dropout_rate * 4294967296.0));
+        p.drop_keep = 1.0f - c.dropout_rate; p.drop_scale = 1.0f / p.drop_keep;
+        p.drop_k0 = c.dropout_seed_lo; p.drop_k1 = c.dropout_seed_hi; p.drop_step = t->steps_done;
+    }
     p.stamps = (long long *)(t->ws + t->oT);
 }
 }  // namespace
@@ -1428,7 +1435,7 @@ int cem_trainer_create(const cem_train_config_t *cfg, void *workspace, size_t wo
     }
     {   // the tile kernel keeps every layer's activations in LDS: (n_layers + 5) x 8 KB, beyond 48 KB only with the runtime's leave
         const size_t lds = (size_t)(cfg->n_layers + 5) * CEM_TT_NB * CEM_TT_BLK;
-        t->tile_kernel = cfg->n_layers <= CEM_TT_MAXL && cfg->units <= CEM_U && cfg->activation == CEM_ACT_RELU &&
+        t->tile_kernel = cfg->n_layers <= CEM_TT_MAXL && cfg->units <= CEM_U && cfg->activation == CEM_ACT_RELU && cfg->dropout_rate == 0.f &&
                          std::getenv("CEM_TRAIN_GEMM_KERNEL") == nullptr;   // the tile kernel is 8 blocks wide and relu only
         hipError_t e = hipSuccess;
         if (t->tile_kernel) switch (cfg->n_layers) {
@@ -1459,6 +1466,7 @@ int cem_trainer_set_state(cem_trainer_t *t, const float *weights, const float *m
     if (m) HIPCHK(hipMemcpyAsync(t->ws + t->oM, m, bytes, hipMemcpyHostToDevice, t->stream)); else HIPCHK(hipMemsetAsync(t->ws + t->oM, 0, bytes, t->stream));
     if (v) HIPCHK(hipMemcpyAsync(t->ws + t->oV, v, bytes, hipMemcpyHostToDevice, t->stream)); else HIPCHK(hipMemsetAsync(t->ws + t->oV, 0, bytes, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
+    t->steps_done = 0;                               // a new state: the Dropout step index restarts with it
     return CEM_OK;
 }
 
@@ -1481,6 +1489,7 @@ int cem_trainer_step(cem_trainer_t *t, const float *x_dev, const float *y_dev, c
     TrainParams p; fill_train_params(t, p);
     p.x = x_dev; p.y = y_dev; p.perm = perm_dev; p.nperm = nperm; p.offset = offset; p.Bt = bt; p.chunk = bt; p.lr_t = lr_t; p.loss_out = loss_dev; p.train = 1;
     launch_train_step(t, p);
+    t->steps_done += 1;
     const size_t n4 = (size_t)p.E * p.nat / 4;
     const unsigned adam_grid = (unsigned)std::min<size_t>(std::max<size_t>((n4 + 255) / 256, 1), 2048);
     hipLaunchKernelGGL(cem_adam_kernel, dim3(adam_grid), dim3(256), 0, t->stream, p);

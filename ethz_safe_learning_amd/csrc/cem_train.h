@@ -39,6 +39,8 @@ struct TrainParams {
     float *loss_out;             // train: [E] loss share of each member; eval: [E][2] raw sums (log term, squared term)
     int32_t train;
     int32_t act;                 // enum cem_activation of the hidden layers (the tile kernel is relu only: cem_capi.hip routes the others here)
+    uint32_t drop_thresh, drop_step, drop_k0, drop_k1;   // training-time Dropout (GemmEpi): rate * 2^32 (0 = none), this step's index, the key
+    float drop_scale, drop_keep;
     long long *stamps;           // [32] phase stamps (member 0), written by -DCEM_STAMPS diagnostic builds only
 };
 
@@ -82,7 +84,30 @@ struct GemmEpi {
     long long *st;         // -DCEM_STAMPS builds: accumulates [8] prologue (first slab in LDS), [9] k loop, [10] epilogue cycles of member 0
     // optional: column sums of B over its K rows (K <= one slab), i.e. the bias gradient sum_r dh[r][n] next to dW = h^T dh
     gptr colsum, colsum1;  // columns n >= nsplit go to colsum1[n - nsplit]
+    // optional training-time Dropout of the layer this GEMM produces (BaseLayer.call, mlp_ensemble.py:15,21; Keras semantics: keep
+    // with probability 1 - rate, kept values scaled by 1 / (1 - rate)): element (row, n) is kept iff word (n & 3) of Philox4x32-7 at
+    // counter (drop_row0 + row, step, (n >> 2) | layer << 8 | 3 << 16, member), key (seed_lo, seed_hi), is >= drop_thresh = rate * 2^32.
+    // The backward gate needs no mask: a dropped unit's stored output is exactly 0, a kept one's is f(z) / (1 - rate).
+    uint32_t drop_thresh;  // 0: no dropout
+    float drop_scale, drop_keep;           // 1 / (1 - rate), 1 - rate
+    uint32_t drop_step, drop_c2, drop_member, drop_k0, drop_k1;
+    int drop_row0;
 };
+
+__device__ __forceinline__ float cem_dropout_fwd(const GemmEpi &e, const int row, const int n, const float v)
+{
+    uint32_t c0 = (uint32_t)(e.drop_row0 + row), c1 = e.drop_step, c2 = (uint32_t)(n >> 2) | e.drop_c2, c3 = e.drop_member;
+    philox4x32_7(c0, c1, c2, c3, e.drop_k0, e.drop_k1);
+    const uint32_t wsel = (n & 3) == 0 ? c0 : ((n & 3) == 1 ? c1 : ((n & 3) == 2 ? c2 : c3));
+    return wsel >= e.drop_thresh ? v * e.drop_scale : 0.f;
+}
+// d * (d output / d pre-activation) of a hidden layer given its STORED output h (after activation and dropout)
+__device__ __forceinline__ float cem_layer_gate(const GemmEpi &e, const float d, const float h)
+{
+    if (e.drop_thresh == 0u) return e.relu <= 1 ? (h > 0.f ? d : 0.f) : cem_activation_gate(e.relu - 1, d, h);
+    if (h == 0.f) return 0.f;                                  // dropped (or a kink / zero of f: a set of measure zero)
+    return cem_activation_gate(e.relu - 1, d, h * e.drop_keep) * e.drop_scale;
+}
 
 // operand split of the fused head GEMMs: B(k, n) comes from B1 at (k - ksplit, n) for k >= ksplit or at (k, n - nsplit) for
 // n >= nsplit; A(m, k) from A1 at (m, k - ksplit).  Unused splits are INT_MAX.
@@ -228,8 +253,11 @@ __device__ __attribute__((noinline)) void wg_gemm_t(const int M, const int N, co
                         const int mI = m0 + 16 * rb + 64 * rk + 4 * kq + i, n = n0 + CW * ch + 16 * jn + li;
                         float v = acc[rk][jn][i];
                         if (e.bias) v = v + bia[jn];
-                        if (e.gate) v = e.relu <= 1 ? (gat[rk][i][jn] > 0.f ? v : 0.f) : cem_activation_gate(e.relu - 1, v, gat[rk][i][jn]);
-                        else if (e.relu) v = e.relu == 1 ? fmaxf(v, 0.f) : cem_activation_fwd(e.relu - 1, v);
+                        if (e.gate) v = cem_layer_gate(e, v, gat[rk][i][jn]);
+                        else if (e.relu) {
+                            v = e.relu == 1 ? fmaxf(v, 0.f) : cem_activation_fwd(e.relu - 1, v);
+                            if (e.drop_thresh) v = cem_dropout_fwd(e, mI, n, v);
+                        }
                         if (mI < M && n < N) (n < sp.nsplit ? e.out : e.out1)[(mI < M ? mI : M - 1) * e.ldo + (n < sp.nsplit ? n : n - sp.nsplit)] = v;
                     }
 #ifdef CEM_STAMPS
@@ -351,8 +379,11 @@ __device__ __attribute__((noinline)) void wg_gemm_r16_deep(const int M, const in
         const int mI = 4 * kq + i;
         float v = acc[i];
         if (e.bias) v = v + bia;
-        if (e.gate) v = e.relu <= 1 ? (gat[i] > 0.f ? v : 0.f) : cem_activation_gate(e.relu - 1, v, gat[i]);
-        else if (e.relu) v = e.relu == 1 ? fmaxf(v, 0.f) : cem_activation_fwd(e.relu - 1, v);
+        if (e.gate) v = cem_layer_gate(e, v, gat[i]);
+        else if (e.relu) {
+            v = e.relu == 1 ? fmaxf(v, 0.f) : cem_activation_fwd(e.relu - 1, v);
+            if (e.drop_thresh) v = cem_dropout_fwd(e, mI, n, v);
+        }
         if (mI < M && n < N) (n < sp.nsplit ? e.out : e.out1)[mI * e.ldo + (n < sp.nsplit ? n : n - sp.nsplit)] = v;
     }
 #ifdef CEM_STAMPS
@@ -460,7 +491,12 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
         const float *hin = l == 0 ? xs : hs + (size_t)(l - 1) * CEM_TROWS * S;
         float *hout = hs + (size_t)l * CEM_TROWS * S;
         const float *Wl = W + offW(l), *bl = W + offb(l);
-        wg_gemm(Bt, U, l == 0 ? D : U, (gcptr)hin, S, 1, (gcptr)Wl, U, 1, GemmEpi{(gptr)hout, S, (gcptr)bl, nullptr, 0, 1 + p.act, nullptr, nullptr, p.stamps, nullptr, nullptr}, CEM_NOSPLIT);     // f(h W + b), f = relu unless configured otherwise
+        GemmEpi fe{(gptr)hout, S, (gcptr)bl, nullptr, 0, 1 + p.act, nullptr, nullptr, p.stamps, nullptr, nullptr};      // f(h W + b), f = relu unless configured otherwise
+        if (p.train && p.drop_thresh) {                                       // Dropout(training=True), mlp_ensemble.py:21,138
+            fe.drop_thresh = p.drop_thresh; fe.drop_scale = p.drop_scale; fe.drop_keep = p.drop_keep; fe.drop_step = p.drop_step;
+            fe.drop_c2 = ((uint32_t)l << 8) | (3u << 16); fe.drop_member = (uint32_t)m; fe.drop_k0 = p.drop_k0; fe.drop_k1 = p.drop_k1; fe.drop_row0 = row0;
+        }
+        wg_gemm(Bt, U, l == 0 ? D : U, (gcptr)hin, S, 1, (gcptr)Wl, U, 1, fe, CEM_NOSPLIT);
     }
     CEM_TR_STAMP(2);
     const float *hL = hs + (size_t)(L - 1) * CEM_TROWS * S;
@@ -502,7 +538,7 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
     // dh_L = (dmu Wmu^T + dv Wvar^T) * relu'(h_L): the relu mask rides in the epilogue of the GEMM that completes dh
     // dh_L = ([dmu | dv] [W_mu | W_var]^T) * relu'(h_L): one GEMM over K = 2O; the relu mask rides in its epilogue
     wg_gemm(Bt, U, 2 * O, (gcptr)dmu, S, 1, (gcptr)(W + oWmu), 1, O,
-            GemmEpi{(gptr)dha, S, nullptr, (gcptr)hL, S, 1 + p.act, nullptr, nullptr, p.stamps, nullptr, nullptr}, GemmSplit{(gcptr)dv, (gcptr)(W + oWv), O, 0x7fffffff});
+            GemmEpi{(gptr)dha, S, nullptr, (gcptr)hL, S, 1 + p.act, nullptr, nullptr, p.stamps, nullptr, nullptr, p.drop_thresh, p.drop_scale, p.drop_keep}, GemmSplit{(gcptr)dv, (gcptr)(W + oWv), O, 0x7fffffff});
     CEM_TR_STAMP(6);
     float *dcur = dha, *dnext = dhb;
     for (int l = L - 1; l >= 0; --l) {
@@ -510,7 +546,7 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
         const int in = l == 0 ? D : U;
         wg_gemm(in, U, Bt, (gcptr)hin, 1, S, (gcptr)dcur, S, 1, GemmEpi{(gptr)(G + offW(l)), U, nullptr, nullptr, 0, 0, nullptr, nullptr, p.stamps, (gptr)(G + offb(l)), nullptr}, CEM_NOSPLIT);   // dW_l = h_{l-1}^T dh_l, db_l = column sums of dh_l
         if (l > 0) {
-            wg_gemm(Bt, U, U, (gcptr)dcur, S, 1, (gcptr)(W + offW(l)), 1, U, GemmEpi{(gptr)dnext, S, nullptr, (gcptr)hin, S, 1 + p.act, nullptr, nullptr, p.stamps, nullptr, nullptr}, CEM_NOSPLIT);   // dh_{l-1} = (dh_l W_l^T) relu'
+            wg_gemm(Bt, U, U, (gcptr)dcur, S, 1, (gcptr)(W + offW(l)), 1, U, GemmEpi{(gptr)dnext, S, nullptr, (gcptr)hin, S, 1 + p.act, nullptr, nullptr, p.stamps, nullptr, nullptr, p.drop_thresh, p.drop_scale, p.drop_keep}, CEM_NOSPLIT);   // dh_{l-1} = (dh_l W_l^T) relu'
             float *t = dcur; dcur = dnext; dnext = t;
         }
     }

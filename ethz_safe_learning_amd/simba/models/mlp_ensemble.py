@@ -27,9 +27,10 @@ class MlpEnsemble(object):
         from ...planner import activation_code
         self.activation = self.mlp_params.get('activation', 'tf.nn.relu')       # the reference evals this string (mlp_ensemble.py:14)
         activation_code(self.activation)                                         # raises NotImplementedError for what is not built
-        if float(self.mlp_params.get('dropout_rate', 0.0)) != 0.0:
-            raise NotImplementedError('dropout_rate != 0 is not built: the device trainer (cem_train_tile.h) has no dropout mask; '
-                                      'config/models.yaml ships 0.0, where the reference\'s Dropout layer is the identity (mlp_ensemble.py:21)')
+        self.dropout_rate = float(self.mlp_params.get('dropout_rate', 0.0))       # Dropout after every hidden layer, training_step only (mlp_ensemble.py:15,21,138)
+        if not 0.0 <= self.dropout_rate < 1.0:
+            raise ValueError('dropout_rate must be in [0, 1)')
+        self._dropout_seed = 0 if seed is None else int(seed)
         rng = np.random.default_rng(seed)
         self._weights = [self._init_member(rng) for _ in range(ensemble_size)]
         self.version = 0
@@ -77,7 +78,8 @@ class MlpEnsemble(object):
         from ...trainer import CemTrainer
         if getattr(self, '_trainer', None) is None:
             self._trainer = CemTrainer(self.inputs_dim, self.outputs_dim, self.mlp_params['units'], self.mlp_params['n_layers'],
-                                       self.ensemble_size, batch_size=self.batch_size, device=device, activation=self.activation)
+                                       self.ensemble_size, batch_size=self.batch_size, device=device, activation=self.activation,
+                                       dropout_rate=self.dropout_rate, dropout_seed=self._dropout_seed)
             self._trainer_version = None
         if self._trainer_version != self.version:           # weights were replaced from outside: Adam moments restart
             self._trainer.set_state(self._weights)

@@ -35,7 +35,7 @@ class CemTrainer:
     reference mlp_ensemble.py:113-117)."""
 
     def __init__(self, inputs_dim, outputs_dim, units, n_layers, ensemble_size, batch_size=64, beta1=0.9, beta2=0.999,
-                 epsilon=1e-5, clipvalue=1.0, device='cuda:0', activation='relu'):
+                 epsilon=1e-5, clipvalue=1.0, device='cuda:0', activation='relu', dropout_rate=0.0, dropout_seed=0):
         import torch
         self._torch = torch
         self.lib = _capi.load()
@@ -49,6 +49,9 @@ class CemTrainer:
         c.batch_size, c.beta1, c.beta2, c.epsilon, c.clipvalue = batch_size, beta1, beta2, epsilon, clipvalue
         from .planner import activation_code
         c.activation = activation_code(activation)
+        c.dropout_rate = float(dropout_rate)                 # mlp_params['dropout_rate']: active in training_step only (mlp_ensemble.py:21,138)
+        c.dropout_seed_lo, c.dropout_seed_hi = int(dropout_seed) & 0xFFFFFFFF, (int(dropout_seed) >> 32) & 0xFFFFFFFF
+        self.dropout_rate, self.dropout_seed = float(dropout_rate), int(dropout_seed)
         self.ccfg = c
         self.device = torch.device(device)
         nbytes = self.lib.cem_trainer_workspace_bytes(C.byref(c))

@@ -252,6 +252,11 @@ typedef struct cem_train_config {
     int32_t inputs_dim, outputs_dim, units, n_layers, ensemble_size;
     int32_t batch_size;           /* rows per member per step, <= 64 (config/models.yaml:4) */
     int32_t activation;           /* enum cem_activation */
+    float dropout_rate;           /* mlp_params['dropout_rate'] (config/models.yaml:13; the shipped value is 0): Dropout after every hidden layer in
+                                   * training_step only (mlp_ensemble.py:15,21,138); 0 <= rate < 1.  The keep mask of training step s (0-based,
+                                   * counted from cem_trainer_create / cem_trainer_set_state) is a pure function of (dropout_seed, s, member,
+                                   * layer, row of the minibatch, unit): cem_train.h GemmEpi */
+    uint32_t dropout_seed_lo, dropout_seed_hi;
     float beta1, beta2, epsilon, clipvalue;
 } cem_train_config_t;
 typedef struct cem_trainer cem_trainer_t;

@@ -210,3 +210,48 @@ def test_training_steps_with_other_activations(E, D, O, L, bt, units, activation
         m['activation'] = activation
     ref_vl = o.validation_loss(gw64, X[:100].astype(np.float64), Y[:100].astype(np.float64))
     assert abs(vl - ref_vl) <= 1e-5 * max(1.0, abs(ref_vl))
+
+
+@pytest.mark.parametrize('activation,rate', [('relu', 0.2), ('tf.nn.tanh', 0.35), ('tf.nn.elu', 0.1)])
+def test_training_steps_with_dropout(activation, rate):
+    """mlp_params['dropout_rate'] != 0 (models.yaml:13; Dropout after every hidden layer in training_step, mlp_ensemble.py:15,21,138):
+    the device draws the keep masks from Philox keyed (seed, step, member, layer, row, unit); the oracle rebuilds exactly those masks
+    in numpy (oracle.dropout_masks) and runs its manual backward pass with them.  validation_step has no dropout."""
+    import torch
+    from ethz_safe_learning_amd.trainer import CemTrainer
+    E, D, O, L, bt, units, seed = 2, 62, 60, 3, 50, 96, 0x1234567890
+    pb, X, Y, rng = _setup(E, D, O, L, seed=21, units=units, activation=activation)
+    tr = CemTrainer(D, O, units, L, E, batch_size=64, activation=activation, dropout_rate=rate, dropout_seed=seed)
+    tr.set_state(pb['weights'])
+    w64 = o.cast_weights(pb['weights'], np.float64)
+    ms64, vs64 = o.zeros_like_weights(w64), o.zeros_like_weights(w64)
+    w_nodrop = o.cast_weights(pb['weights'], np.float64)
+    x_dev, y_dev = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()
+    lr = 0.00025
+    for t in range(1, 4):
+        perm = np.stack([rng.permutation(X.shape[0]) for _ in range(E)]).astype(np.int32)
+        loss_dev = torch.zeros(E, device='cuda')
+        tr.step(x_dev, y_dev, torch.from_numpy(perm).cuda(), 3 * t, bt, lr, loss_dev)
+        tr.synchronize()
+        idx = perm[:, 3 * t:3 * t + bt]
+        masks = [o.dropout_masks(seed, t - 1, m, L, bt, units, rate) for m in range(E)]
+        if t == 1:
+            plain = sum(o.member_loss_and_grads(w_nodrop[m], X[idx[m]].astype(np.float64), Y[idx[m]].astype(np.float64), E)[0] for m in range(E))
+        ref = o.training_step(w64, ms64, vs64, X[idx].astype(np.float64), Y[idx].astype(np.float64), lr, t, masks)
+        got = float(loss_dev.sum().item())
+        assert abs(got - ref) <= 1e-5 * max(1.0, abs(ref)), (activation, t, got, ref)
+        if t == 1:
+            assert abs(ref - plain) > 1e-4, 'the masks did not change the loss: dropout is not in the forward pass'
+    worst = 0.0
+    for a, b in zip(tr.get_weights(), w64):
+        for ka, kb in zip(o._flat_params(a), o._flat_params(b)):
+            worst = max(worst, float(np.abs(ka - kb).max()))
+    print('%s dropout %.2f: max |w_gpu - w_f64| after 3 Adam steps: %.3g' % (activation, rate, worst))
+    assert worst <= 2e-5
+    vl = tr.validation_loss(x_dev[:100], y_dev[:100])                                    # training=False: no masks
+    gw64 = o.cast_weights(tr.get_weights(), np.float64)
+    for m in gw64:
+        if activation != 'relu':
+            m['activation'] = activation
+    ref_vl = o.validation_loss(gw64, X[:100].astype(np.float64), Y[:100].astype(np.float64))
+    assert abs(vl - ref_vl) <= 1e-5 * max(1.0, abs(ref_vl))

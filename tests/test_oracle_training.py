@@ -80,3 +80,37 @@ def test_training_reduces_loss_on_a_learnable_problem():
         last = loss
     assert last < first - 0.5
     assert o.validation_loss(w, X, Y) < first
+
+
+def test_dropout_masks_and_masked_gradients():
+    """mlp_params['dropout_rate'] (models.yaml:13): Keras Dropout keeps a unit with probability 1 - rate and scales it by
+    1 / (1 - rate), in training_step only.  The masks are a pure function of (seed, step, member, layer, row, unit); the manual
+    backward pass with masks is checked against finite differences of the masked forward."""
+    m = o.dropout_masks(seed=7, step=3, member=1, n_layers=3, rows=64, units=128, rate=0.2)
+    assert len(m) == 3 and m[0].shape == (64, 128)
+    vals = np.unique(np.concatenate([x.ravel() for x in m]))
+    assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1.25) < 1e-6
+    keep = np.mean([np.mean(x > 0) for x in m])
+    assert abs(keep - 0.8) < 0.01
+    assert not np.array_equal(m[0], m[1])                                               # layers draw different masks
+    assert not np.array_equal(m[0], o.dropout_masks(7, 4, 1, 3, 64, 128, 0.2)[0])       # so do steps
+    assert not np.array_equal(m[0], o.dropout_masks(7, 3, 0, 3, 64, 128, 0.2)[0])       # and members
+    assert np.array_equal(m[0], o.dropout_masks(7, 3, 1, 3, 64, 128, 0.2)[0])           # and nothing else
+    w, x, y = _tiny(activation='tf.nn.tanh')
+    masks = o.dropout_masks(1, 0, 0, 2, x.shape[1], 8, 0.3)
+    loss, g = o.member_loss_and_grads(w[0], x[0], y[0], 2, masks)
+    loss0, _ = o.member_loss_and_grads(w[0], x[0], y[0], 2)
+    assert abs(loss - loss0) > 1e-6
+    eps = 1e-6
+    rng = np.random.default_rng(2)
+    for name, arr, grad in [('W0', w[0]['W'][0], g['W'][0]), ('b0', w[0]['b'][0], g['b'][0]), ('W1', w[0]['W'][1], g['W'][1]), ('W_var', w[0]['W_var'], g['W_var'])]:
+        for _ in range(5):
+            idx = tuple(rng.integers(0, s) for s in arr.shape)
+            old = arr[idx]
+            arr[idx] = old + eps
+            lp, _ = o.member_loss_and_grads(w[0], x[0], y[0], 2, masks)
+            arr[idx] = old - eps
+            lm, _ = o.member_loss_and_grads(w[0], x[0], y[0], 2, masks)
+            arr[idx] = old
+            fd = (lp - lm) / (2 * eps)
+            assert abs(fd - grad[idx]) <= 1e-6 * max(1.0, abs(fd)), (name, idx, fd, grad[idx])

@@ -21,7 +21,7 @@ MODELS_YAML = dict(ensemble_size=15, batch_size=64, validation_split=0.2, learni
                    training_steps=5000, mlp_params=dict(n_layers=4, units=128, activation='tf.nn.relu', dropout_rate=0.0))
 
 
-def make_agent_parts(policy_name, seed=0, units=None, activation=None):
+def make_agent_parts(policy_name, seed=0, units=None, activation=None, dropout_rate=None):
     """What MbrlAgent.__init__ does (mbrl_agent.py:27-35,103-118; agent_factory.py:22 injects train_epochs)."""
     env = SyntheticSafetyGym()
     model_params = dict(MODELS_YAML, scale_features=True, train_epochs=10, seed=seed)
@@ -29,6 +29,8 @@ def make_agent_parts(policy_name, seed=0, units=None, activation=None):
         model_params['mlp_params'] = dict(MODELS_YAML['mlp_params'], units=units)
     if activation is not None:                             # models.yaml:12: any string the reference can eval
         model_params['mlp_params'] = dict(model_params['mlp_params'], activation=activation)
+    if dropout_rate is not None:                           # models.yaml:13
+        model_params['mlp_params'] = dict(model_params['mlp_params'], dropout_rate=dropout_rate)
     model = TransitionModel(model='mlp_ensemble', observation_space=env.observation_space, action_space=env.action_space,
                             sampling_propagation=True, **model_params)
     policy_params = dict(POLICIES_YAML[policy_name])
@@ -249,8 +251,10 @@ def test_unknown_activation_is_refused_with_a_reason():
 @pytest.mark.gpu
 def test_model_with_another_activation_fits_and_plans():
     """models.yaml `activation: tf.nn.elu` through the simba classes: MlpEnsemble.fit on the device (the GEMM trainer), then
-    SafeCemMpc.generate_action (the generic rollout kernel) against the oracle on the FITTED weights with that activation."""
-    env, model, pol = make_agent_parts('safe_cem_mpc', seed=5, activation='tf.nn.elu')
+    SafeCemMpc.generate_action (the generic rollout kernel) against the oracle on the FITTED weights with that activation;
+    `dropout_rate: 0.1` rides along (training-time only: the planner's forward passes run with training=False, mlp_ensemble.py:127)."""
+    env, model, pol = make_agent_parts('safe_cem_mpc', seed=5, activation='tf.nn.elu', dropout_rate=0.1)   # Dropout acts in fit only
+    assert model.model.dropout_rate == 0.1
     rng = np.random.default_rng(4)
     obs = rng.normal(0, 0.5, (400, 60)).astype(np.float32)
     acs = rng.uniform(-1, 1, (400, 2)).astype(np.float32)
