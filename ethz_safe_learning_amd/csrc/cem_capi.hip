@@ -155,6 +155,8 @@ void pack_member(const Dims &d, const float *nat, float *out)
 
 // Weight image of one member for cem_rollout_wide_kernel: 1 KB groups [64 lanes][4] in cem_wide_base / cem_wide_groups order;
 // lane (q, j), word r of group (k block kb, output block ob) = W[16 kb + 4 q + r][16 ob + j], zero past the matrix.
+// rows of the per-member feature table (RolloutParams::etab): the wide kernel's hidden layers are up to 256 features = two rows each
+size_t etab_rows(const Dims &d) { return CEM_ET_ROWS + (d.wide ? 2 : 1) * (size_t)d.L; }
 size_t wide_image_floats(const Dims &d) { return (size_t)cem_wide_groups(d.L, d.KB_in, (d.U + 15) / 16, d.KB_obs) * 256; }
 void pack_member_wide(const Dims &d, const float *nat, float *out)
 {
@@ -400,7 +402,7 @@ Layout make_layout(const cem_config_t *c, const Dims &d, size_t max_tiles)
     l.ndelta = take(CEM_U * 4);
     l.omask = take(2 * CEM_U * 4);
     l.kind_sel = take(CEM_NKIND * CEM_U * 4);
-    l.etab = take((size_t)d.E * (CEM_ET_ROWS + d.L) * CEM_U * 4);
+    l.etab = take((size_t)d.E * etab_rows(d) * CEM_U * 4);
     l.tiles = take(max_tiles * sizeof(TileDesc));
     l.eps_out = take(CEM_MAX_ACT * 4);
     l.stamps = take(std::max<size_t>(max_tiles * 4 * 8, 128) * sizeof(long long));      // [tiles][4][8] rollout stamps; [64..71] select stamps
@@ -655,7 +657,7 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
     }
     std::vector<float> mn(CEM_U, 0.f), dl(CEM_U, 1.f);
     // the hot kernel's per-member table: identity normaliser and zero biases until set_normaliser / set_weights fill them in
-    const size_t et_rows = CEM_ET_ROWS + d.L;
+    const size_t et_rows = etab_rows(d);
     h->h_etab.assign((size_t)d.E * et_rows * CEM_U, 0.f);
     for (int m = 0; m < d.E; ++m) {
         float *et = &h->h_etab[(size_t)m * et_rows * CEM_U];
@@ -720,6 +722,18 @@ int cem_planner_set_weights(cem_planner_t *h, const float *blob, size_t n_floats
         for (int m = 0; m < d.E; ++m) pack_member_wide(d, blob + (size_t)m * d.nat_member_floats, images.data() + (size_t)m * img);
         HIPCHK(hipMemcpyAsync(h->ws + h->lay.wpack, blob, n_floats * 4, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->ws + h->lay.wpack + align256(n_floats * 4), images.data(), images.size() * 4, hipMemcpyHostToDevice, h->stream));
+        const NatOff no = nat_offsets(d);                // the biases as rows of the per-member table (hidden layers: 256 features = 2 rows)
+        const size_t et_rows = etab_rows(d);
+        for (int m = 0; m < d.E; ++m) {
+            const float *nat = blob + (size_t)m * d.nat_member_floats;
+            float *et = &h->h_etab[(size_t)m * et_rows * CEM_U];
+            std::memset(et + CEM_ET_BMU * CEM_U, 0, 2 * CEM_U * 4);
+            std::memcpy(et + CEM_ET_BMU * CEM_U, nat + no.bmu, d.O * 4);
+            std::memcpy(et + CEM_ET_BVAR * CEM_U, nat + no.bvar, d.O * 4);
+            std::memset(et + CEM_ET_ROWS * CEM_U, 0, (size_t)2 * d.L * CEM_U * 4);
+            for (int l = 0; l < d.L; ++l) std::memcpy(et + (CEM_ET_ROWS + 2 * l) * CEM_U, nat + no.b[l], d.U * 4);
+        }
+        HIPCHK(hipMemcpyAsync(h->ws + h->lay.etab, h->h_etab.data(), h->h_etab.size() * 4, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         h->have_weights = true;
         return CEM_OK;
@@ -739,7 +753,7 @@ int cem_planner_set_weights(cem_planner_t *h, const float *blob, size_t n_floats
     HIPCHK(hipMemcpyAsync(h->ws + h->lay.bias_mu, bmu.data(), bmu.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->ws + h->lay.bias_var, bvar.data(), bvar.size() * 4, hipMemcpyHostToDevice, h->stream));
     {   // the same biases as rows of the hot kernel's per-member table
-        const size_t et_rows = CEM_ET_ROWS + d.L;
+        const size_t et_rows = etab_rows(d);
         for (int m = 0; m < d.E; ++m) {
             float *et = &h->h_etab[(size_t)m * et_rows * CEM_U];
             std::memcpy(et + CEM_ET_BMU * CEM_U, &bmu[(size_t)m * CEM_U], CEM_U * 4);
@@ -768,7 +782,7 @@ int cem_planner_set_normaliser(cem_planner_t *h, const float *imin, const float 
     HIPCHK(hipMemcpyAsync(h->ws + h->lay.nmin, mn.data(), CEM_U * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->ws + h->lay.ndelta, dl.data(), CEM_U * 4, hipMemcpyHostToDevice, h->stream));
     {
-        const size_t et_rows = CEM_ET_ROWS + d.L;
+        const size_t et_rows = etab_rows(d);
         for (int m = 0; m < d.E; ++m) {
             float *et = &h->h_etab[(size_t)m * et_rows * CEM_U];
             std::memcpy(et + CEM_ET_NMIN * CEM_U, mn.data(), CEM_U * 4);
@@ -822,12 +836,14 @@ hipError_t launch_rollout(int rc, int nfw, const RolloutParams &p, int n_tiles, 
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_rollout_wide(const cem_planner *h, const RolloutParams &rp, int n_tiles)
+// mode 0: planning; mode 1: caller-supplied action / noise tensors, trajectory and head-moment outputs
+hipError_t launch_rollout_wide(const cem_planner *h, const RolloutParams &rp, int n_tiles, int mode)
 {
     WideParams wp; wp.r = rp;
-    wp.wnat = (const float *)(h->ws + h->lay.wpack); wp.nat = (uint32_t)h->d.nat_member_floats; wp.U = h->d.U; wp.act = h->cfg.activation;
+    wp.U = h->d.U; wp.act = h->cfg.activation;
     wp.wimg = (const f4 *)(h->ws + h->lay.wpack + align256((size_t)h->d.E * h->d.nat_member_floats * 4)); wp.img_f4 = (uint32_t)(wide_image_floats(h->d) / 4);
-    hipLaunchKernelGGL(cem_rollout_wide_kernel, dim3(n_tiles), dim3(256), CEM_WIDE_SMEM, h->stream, wp);
+    if (mode == 0) hipLaunchKernelGGL(cem_rollout_wide_kernel<0>, dim3(n_tiles), dim3(256), CEM_WIDE_SMEM, h->stream, wp);
+    else hipLaunchKernelGGL(cem_rollout_wide_kernel<1>, dim3(n_tiles), dim3(256), CEM_WIDE_SMEM, h->stream, wp);
     return hipGetLastError();
 }
 
@@ -888,7 +904,7 @@ int enqueue_rollout(cem_planner *h, int it)
     rp.stamps = (long long *)(ws + l.stamps);
     size_t e0 = 0;
     if (h->timing) { e0 = h->ev_kind.size() * 2; h->ev_kind.push_back({(int)e0, 0}); hipEventRecord(get_event(h, e0), h->stream); }
-    if (d.wide) HIPCHK(launch_rollout_wide(h, rp, h->n_tiles));
+    if (d.wide) HIPCHK(launch_rollout_wide(h, rp, h->n_tiles, rp.eps_model ? 1 : 0));
     else if (rp.eps_model) HIPCHK(launch_rollout<1>(h->rc, d.NFW, rp, h->n_tiles, h->stream));
     else if (queued) {
         rp.seg_queue = sp.seg_queue; rp.seg_flags = sp.seg_flags; rp.seg_state = (f4 *)(ws + l.seg_state);
@@ -1230,7 +1246,7 @@ int cem_unfold_sequences(cem_planner_t *h, const float *s0_dev, const float *act
     rp.tiles = dt; rp.s0 = s0_dev; rp.actions = actions_dev; rp.eps_model = eps_model_dev; rp.ret = ret; rp.costs = nullptr;
     rp.traj = traj_out_dev; rp.mu_out = mu_out_dev; rp.sd_out = sd_out_dev;
     rp.H = horizon; rp.Bloc = n_rows; rp.Btot = n_rows; rp.it = 0; rp.variant = 0; rp.check_done = 0;
-    hipError_t e = d.wide ? launch_rollout_wide(h, rp, (int)tiles.size()) : launch_rollout<1>(rc, d.NFW, rp, (int)tiles.size(), h->stream);
+    hipError_t e = d.wide ? launch_rollout_wide(h, rp, (int)tiles.size(), 1) : launch_rollout<1>(rc, d.NFW, rp, (int)tiles.size(), h->stream);
     hipError_t e2 = hipStreamSynchronize(h->stream);
     HIPCHK(e); HIPCHK(e2);
     return CEM_OK;

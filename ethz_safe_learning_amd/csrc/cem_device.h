@@ -797,11 +797,9 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
     if (p.stamps && lane == 0) for (int i = 0; i < 8; ++i) p.stamps[((size_t)tile_idx * 4 + w) * 8 + i] = st_[i];
 #endif
 }
-#undef CEM_BOOKKEEP
-#undef CEM_PART_MIN4
-#undef CEM_PAIR_MIN_STORE
-#undef CEM_RARE_KINDS_AND_STORE
 #undef CEM_LOAD_ACT
+// CEM_BOOKKEEP, CEM_PART_MIN4, CEM_PAIR_MIN_STORE and CEM_RARE_KINDS_AND_STORE stay defined: cem_rollout_wide.h uses them with the
+// same local names (RC = 1) and undefines them.
 
 template <int RC, int NFW, int MODE>
 __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)

@@ -10,7 +10,8 @@ from tests import helpers as hp
 from ethz_safe_learning_amd.trainer import CemTrainer
 
 for units in [int(a) for a in sys.argv[1:]] or [128, 160, 256]:
-    pb = hp.make_problem(60, 2, 5, 4, seed=1, units=units)
+    act = os.environ.get('CEM_WIDE_ACT', 'relu')       # anything but relu runs the generic kernel at any width
+    pb = hp.make_problem(60, 2, 5, 4, seed=1, units=units, activation=act)
     _, cfg = hp.configs(pb, N=2000, H=30, P=5, E=5, k=200, I=5, use_graph=True)
     pl = hp.make_planner(pb, cfg)
     for i in range(12):
@@ -21,6 +22,9 @@ for units in [int(a) for a in sys.argv[1:]] or [128, 160, 256]:
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
     fl = 2 * (62 * units + 3 * units * units + 2 * units * 60) * 5 * 2000 * 30 * 5
     pl.close()
+    if os.environ.get('CEM_WIDE_PLAN_ONLY'):
+        print('units %3d %s: plan %.3f ms (%.1f TFLOP/s of its algorithmic FLOPs)' % (units, act, dt * 1e3, fl / dt / 1e12), flush=True)
+        continue
     tr = CemTrainer(62, 60, units, 4, 15)
     tr.set_state(hp.make_problem(60, 2, 15, 4, seed=1, units=units)['weights'])
     rng = np.random.default_rng(0); n = 4096
