@@ -1,15 +1,27 @@
-// cem_rollout_wide.h — the rollout for hidden layers wider than the fast kernel's 128 units (128 < units <= 256; obs+act <= 128).
+// cem_rollout_wide.h — the GENERIC rollout kernel: hidden layers wider than the fast kernel's 128 units (units <= 256; obs+act <= 128)
+// and hidden activations other than relu at any width.
 //
-// The reference takes any `units` from config/models.yaml:11 (only 128 ships).  cem_rollout_tile keeps a layer's 8 feature blocks
-// in registers and streams pre-packed weights through a ring sized for exactly that; this kernel trades that speed for width:
-// the same tile (16 rows of one member for the whole horizon, 4 waves), the same arithmetic per element, the same Philox keys,
-// the same epilogue and scorer terms — but runtime loops over 16-feature blocks, activations exchanged through LDS at every
-// stage, and weights streamed from a per-member image packed in A-operand order — one 1 KB group per (k block, output block),
-// so a lane's four MFMA steps of a group are ONE 16-byte load (read from the natural layout they were four 4-byte loads of 64-byte
-// rows: 63 -> 77 TFLOP/s at 256 units; the biases still come from the natural blob, which travels with the image).  A layer's products are summed over k blocks in ascending order (the fast kernel visits a wave's
-// own blocks first): the two kernels agree to fp32 rounding, not bit for bit — which kernel runs depends on `units` alone, so
-// shard / tile-plan invariance holds within either.  One instantiation serves planning, explicit noise tensors and the
-// trajectory / head-moment outputs of cem_unfold_sequences (null pointers switch them off).
+// The reference takes any `units` and any activation from config/models.yaml:11-12 (128 / relu ship).  cem_rollout_tile keeps a
+// layer's 8 feature blocks in registers and streams pre-packed weights through a ring sized for exactly that; this kernel trades
+// some of that speed for generality: the same tile (16 rows of one member for the whole horizon, 4 waves), the same arithmetic per
+// element, the same Philox keys, the same epilogue / scorer terms / bookkeeping (cem_rollout_tile's own macros on the same
+// per-member feature table) — but runtime loops over 16-feature blocks, activations exchanged through LDS at every stage, and
+// weights streamed from a per-member image packed in A-operand order: one 1 KB group per (k block, output block), so a lane's four
+// MFMA steps of a group are ONE 16-byte load.  A layer's products are summed over k blocks in ascending order (the fast kernel
+// visits a wave's own blocks first): the two kernels agree to fp32 rounding, not bit for bit — which kernel runs depends on
+// (units, activation) alone, so shard / tile-plan invariance holds within either.
+//
+// What makes it run (round 3; profiles/r03_ab_generic_kernel.txt: 10.3 -> 7.1 ms per B2-shaped plan at 256 units, 0.49 -> 0.67 of the
+// fp32 MFMA peak, 0.82 with four tiles per CU; 160 units 7.1 -> 3.8 ms):
+//  * every load of the steady state is UNCONDITIONAL.  s_waitcnt counts loads in issue order, so a prefetch that sits under a
+//    wave-uniform branch (`if (kb + 1 < nbK) load next`) makes the compiler assume it may not have been issued and wait with
+//    vmcnt(0) before the MFMAs — i.e. for the prefetch itself, every k block.  Indices are clamped into the image instead; a load
+//    past the end of a stage re-reads its last group and is never used.
+//  * the first weight groups AND the biases of the next stage are requested before the barrier that publishes its input, so an
+//    L2 round trip overlaps the barrier wait and the activation epilogue instead of following them.
+//  * the epilogue addresses one buffer resource per table with a single lane-offset VGPR (no 64-bit address pairs held across
+//    the loop): 213 -> 126 VGPRs, four workgroups per CU instead of two.
+//  * MODE 0 (planning) and MODE 1 (caller-supplied tensors, trajectory / head-moment outputs) are separate instantiations.
 #pragma once
 #include "cem_device.h"
 
