@@ -118,7 +118,7 @@ def comm_ranks_or_none(pl):
         return None
 
 
-def b5_leg(torch, dist, pb, G, rank, dev, native, steps, warmup, rehearse_world=0):
+def b5_leg(torch, dist, pb, G, rank, dev, native, steps, warmup, rehearse_world=0, ctl_dev=None):
     """BASELINE.json configs[4], strong-scaled: N = 65536 candidates (K = P = E = 5, H = 30, I = 5, k = 6554) sharded over the G
     ranks of this run, one all-gather of the scores per CEM iteration.  Timed like the headline: barrier + synchronize on both
     sides, max over ranks.  `rehearse_world` = R > 0 (CEM_BENCH_B5_REHEARSAL=R on a one-GPU box): this process plays rank 0 of R —
@@ -176,7 +176,7 @@ def b5_leg(torch, dist, pb, G, rank, dev, native, steps, warmup, rehearse_world=
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=ctl_dev or dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert it == I and np.all(np.isfinite(a))
@@ -225,15 +225,23 @@ def main():
     # CEM_BENCH_FORCE_DIST=1: run the multi-rank leg (process group, stepwise plan with the score all-gather, max-over-ranks
     # timing) with however many ranks there are, even one — the only way to rehearse that leg on a one-GPU box
     distributed = G > 1 or os.environ.get('CEM_BENCH_FORCE_DIST') == '1'
+    # CEM_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box, tests/test_gpu_multirank.py): every rank uses cuda:0, gloo carries the
+    # barrier / max-over-ranks (RCCL refuses two ranks on one device) and CEM_RCCL_LIBRARY names the stand-in for the collective
+    share_gpu = os.environ.get('CEM_BENCH_SHARE_GPU') == '1'
     if distributed:
         assert world == G, 'launch with torch.distributed.run --nproc-per-node %d' % G
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if share_gpu:
+            torch.cuda.set_device(0)
+            dist.init_process_group('gloo')
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     else:
         dist = None
         torch.cuda.set_device(0)
-    dev = 'cuda:%d' % (local_rank if distributed else 0)
+    dev = 'cuda:%d' % (local_rank if distributed and not share_gpu else 0)
+    ctl_dev = 'cpu' if share_gpu else dev               # where the few control tensors of the process group live
 
     obs, act, K, H, I = 60, 2, 5, 30, 5
     N = args.n_per_gpu * G
@@ -261,7 +269,7 @@ def main():
         except Exception as e:                        # e.g. librccl not loadable from the library, ncclCommInitRank refused
             sys.stderr.write('rank %d: native RCCL exchange unavailable (%s); using the host-stepped exchange\n' % (rank, e))
             ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        flag = torch.tensor([ok], dtype=torch.int32, device=ctl_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             if ok:
@@ -290,7 +298,7 @@ def main():
     dt = time.perf_counter() - t0
     step_ms = 1e3 * np.diff(np.array(stamps))
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert it == I and np.all(np.isfinite(a))
@@ -360,7 +368,7 @@ def main():
         if native:
             pl.comm_destroy()                          # one communicator at a time
         out['b5'] = b5_leg(torch, dist, pb, G, rank, dev, native, steps=min(args.steps, 20), warmup=min(max(args.warmup, 2), 5),
-                           rehearse_world=rehearse if G == 1 else 0)
+                           rehearse_world=rehearse if G == 1 else 0, ctl_dev=ctl_dev)
     if rank == 0 and G == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     if rank == 0:

@@ -88,7 +88,7 @@ Dims make_dims(const cem_config_t *c)
     d.Nloc = d.N / d.W; d.n_off = d.R * d.Nloc; d.Bloc = d.P * d.Nloc; d.Btot = d.P * d.N;
     d.KB_in = (d.Din + 15) / 16; d.KB_obs = (d.O + 15) / 16; d.NFW = (d.KB_in + 3) / 4; d.KF0 = 4 * d.NFW;
     d.act_q0 = d.O / 4; d.act_nq = (d.Din + 3) / 4 - d.act_q0;
-    d.wide = d.U > CEM_U || c->activation != CEM_ACT_RELU;   // the tuned kernels: units <= 128 and relu; everything else takes the generic rollout kernel
+    d.wide = d.U > CEM_U || c->activation != CEM_ACT_RELU || std::getenv("CEM_FORCE_GENERIC_ROLLOUT") != nullptr;   // (the variable: a diagnostic, scripts/sweep_configs.py)   // the tuned kernels: units <= 128 and relu; everything else takes the generic rollout kernel
     uint32_t off = 0;
     for (int w = 0; w < 4; ++w) {
         int g = d.KF0 + CEM_NG * (d.L - 1);
@@ -441,9 +441,16 @@ Rccl *rccl()
     static Rccl r;
     static std::once_flag once;                      // two handles may ask at once (one per env thread)
     std::call_once(once, [] {
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (r.lib) break;
+        // CEM_RCCL_LIBRARY: load THIS file instead (a site's own RCCL build; tests/fakes/libfake_rccl.so, the shared-memory
+        // stand-in with which several ranks share a one-GPU box).  Set and not loadable: no fallback, the error says so.
+        if (const char *over = std::getenv("CEM_RCCL_LIBRARY")) {
+            r.lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+            if (!r.lib) std::fprintf(stderr, "cem_mpc: CEM_RCCL_LIBRARY=%s: %s\n", over, dlerror());
+        } else {
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (r.lib) break;
+            }
         }
         if (r.lib) {
             r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");

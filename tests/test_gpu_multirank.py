@@ -1,0 +1,99 @@
+"""The library's multi-rank path with world_size > 1 ON HARDWARE, several ranks sharing the one GPU of a lease.
+
+RCCL refuses two ranks on one device (scripts/try_two_ranks_one_gpu.py), so the collective — and only the collective — is
+replaced by tests/fakes/libfake_rccl.so (CEM_RCCL_LIBRARY): a shared-memory all-gather built from stream operations.  Everything
+else is the product path: cem_planner_comm_init, candidate shards, the ncclAllGather call inside cem_planner_plan, the captured
+hipGraph with the collective in it, the replicated select, cem_plan_exchange in the stepwise form, and bench.py's multi-rank
+leg.  Pass criterion: every rank returns bit for bit what a single-rank planner of the same configuration returns."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE = os.path.join(ROOT, 'tests', 'fakes', 'libfake_rccl.so')
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture(scope='module')
+def fake_rccl():
+    r = subprocess.run(['make', '-C', os.path.join(ROOT, 'tests', 'fakes')], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0 and os.path.exists(FAKE), r.stdout
+    return FAKE
+
+
+def _launch(world, script, args, env_extra, timeout=300):
+    env = dict(os.environ)
+    env.update(env_extra)
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), script] + args
+    return subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout, cwd=ROOT)
+
+
+CASES = [
+    # one-workgroup select, safe variant (costs travel with the shard), ragged shard sizes for the tile plan (N / W = 256)
+    dict(name='w2_safe', world=2, N=512, H=10, k=51, I=3, variant='safe', seed=83, plan_seed=23, calls=4),
+    # three ranks, a population the fused multi-workgroup select takes (N >= 24000), elite set spread over all shards
+    dict(name='w3_fused_select', world=3, N=24576, H=6, k=2457, I=2, variant='cem', seed=84, plan_seed=5, calls=3),
+    # the 8-launch select chain under the graph, two ranks
+    dict(name='w2_chain_select', world=2, N=4096, H=8, k=409, I=3, variant='cem', seed=85, plan_seed=9, calls=3, select_mode=2),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c['name'] for c in CASES])
+def test_every_rank_of_a_sharded_plan_equals_the_single_rank_plan(case, fake_rccl, tmp_path):
+    from tests import helpers as hp
+    # reference first (this process holds the GPU too: world + 1 processes on the card, within the box's limit of 6)
+    pb = hp.make_problem(seed=case['seed'])
+    _, cfg = hp.configs(pb, N=case['N'], H=case['H'], P=5, E=5, k=case['k'], I=case['I'], variant=case['variant'], post=0.3, noise=0.02,
+                        use_graph=True, select_mode=case.get('select_mode', 0))
+    ref = hp.make_planner(pb, cfg)
+    expect = []
+    for c in range(case['calls']):
+        a, s, it = ref.plan(pb['state'], seed=case['plan_seed'], call=c)
+        expect.append((a, np.float32(s), it, ref.mu_sigma().cpu().numpy(), np.sort(ref.elite_idx().cpu().numpy())))
+    ref.close()
+
+    r = _launch(case['world'], os.path.join(ROOT, 'tests', 'multirank_worker.py'), [str(tmp_path), json.dumps(case)],
+                {'CEM_RCCL_LIBRARY': fake_rccl})
+    assert r.returncode == 0, r.stdout[-4000:]
+    for rank in range(case['world']):
+        got = np.load(os.path.join(str(tmp_path), 'rank%d.npz' % rank))
+        st = json.load(open(os.path.join(str(tmp_path), 'rank%d.json' % rank)))['graph_status']
+        assert st[0] == 'eager' and all(x == 'graph' for x in st[1:]), st      # the collective was captured and replayed
+        for c in range(case['calls']):
+            a, s, it, ms, el = expect[c]
+            np.testing.assert_array_equal(got['action%d' % c], a, err_msg='rank %d call %d' % (rank, c))
+            assert got['score%d' % c] == s and got['iters%d' % c] == it
+            np.testing.assert_array_equal(got['musig%d' % c], ms)
+            np.testing.assert_array_equal(got['elite%d' % c], el)
+        np.testing.assert_array_equal(got['action_step'], expect[1][0])
+        assert got['score_step'] == expect[1][1]
+
+
+def test_bench_multi_rank_leg_two_ranks_on_one_gpu(fake_rccl):
+    """bench.py --gpus 2 as the driver launches it, except that both ranks use cuda:0 (CEM_BENCH_SHARE_GPU=1: gloo carries the
+    barrier / max-over-ranks, the fake carries the all-gather).  The line must be the multi-rank one: native exchange, weak
+    scaling, the B5 leg present.  (Its numbers mean nothing: two ranks time-share one GPU.)"""
+    r = _launch(2, os.path.join(ROOT, 'bench.py'), ['--gpus', '2', '--steps', '3', '--warmup', '2', '--no-cpu-baseline'],
+                {'CEM_RCCL_LIBRARY': fake_rccl, 'CEM_BENCH_SHARE_GPU': '1'}, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{') and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-4000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['candidates_per_gpu'] == 2000 and 'N=4000' in d['config']['workload']
+    assert d['config']['exchange'].startswith('ncclAllGather inside the library'), d['config']
+    assert d['config']['hip_graph'] is True
+    assert d['value'] > 0 and d['b5']['n_ranks'] == 2 and d['b5']['candidates_per_rank'] == 32768 and d['b5']['n_ranks_seen_by_rccl'] == 2
+    assert d['b5']['exchange'].startswith('ncclAllGather inside the library') and d['b5']['hip_graph'] is True
