@@ -1,28 +1,53 @@
 #!/usr/bin/env python3
-"""Soak: 60 x (MlpEnsemble.fit + 20 generate_action calls) on one pair of handles; device memory (hipMemGetInfo), torch's allocator
-and the host RSS must stay flat — the trainer keeps every epoch's permutation tensor alive until the fit's final synchronize,
-the planner handle cache re-stages weights after every fit.  usage: python scripts/soak.py"""
-import os, sys, time, gc
+"""Soak run: tens of thousands of plans through each kernel family on one handle each (B2 cem / the floating-segment kernel, B2 safe,
+a generic-kernel shape, a handle that is re-staged with new weights every 500 plans as the agent does after `fit`), checking that
+nothing drifts: a fixed (seed, call) is re-planned every 1000 plans and must return the same bits, free device memory must not
+shrink, no plan may report a device fault.  usage: python scripts/soak.py [seconds per leg, default 40]"""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from tests.test_simba_api import make_agent_parts
-env, model, pol = make_agent_parts('safe_cem_mpc', seed=1)
-rng = np.random.default_rng(0)
-n = 3000
-obs = rng.normal(0, 0.3, (n, 60)).astype(np.float32); act = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
-A = rng.normal(0, 0.02, (62, 60)).astype(np.float32)
-nxt = obs + np.concatenate([obs, act], 1) @ A
-x = np.concatenate([obs, act], 1)
-model.model.training_steps = 300
-def rss():
-    import psutil; return psutil.Process().memory_info().rss / 2**20
-free0 = None
-for it in range(60):
-    model.fit(x, nxt)
-    for i in range(20): pol.generate_action(obs[i])
-    if it % 10 == 0:
-        torch.cuda.synchronize(); gc.collect()
-        free, total = torch.cuda.mem_get_info()
-        used = (total - free) / 2**20
-        if free0 is None: free0 = used
-        print('iter %3d: device used %.0f MiB (%+.0f), torch allocated %.0f MiB, host rss %.0f MiB' % (it, used, used - free0, torch.cuda.memory_allocated() / 2**20, rss()), flush=True)
+import numpy as np
+import torch
+from tests import helpers as hp
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
+
+
+def leg(name, pb, cfg, restage_every=0):
+    pl = hp.make_planner(pb, cfg)
+    ref = pl.plan(pb['state'], seed=11, call=7)
+    free0 = torch.cuda.mem_get_info()[0]
+    rng = np.random.default_rng(0)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget:
+        st = pb['state'] + 0.01 * rng.standard_normal(pb['state'].shape).astype(np.float32)
+        a, s, it = pl.plan(st, seed=3, call=n)
+        assert np.all(np.isfinite(a)) and np.isfinite(s), (name, n)
+        n += 1
+        if restage_every and n % restage_every == 0:
+            pl.set_weights(pb['weights'])                       # same values: the probe below must still match
+            pl.set_normaliser(pb['inputs_min'], pb['inputs_max'])
+        if n % 1000 == 0:
+            a, s, it = pl.plan(pb['state'], seed=11, call=7)
+            assert np.array_equal(a, ref[0]) and s == ref[1] and it == ref[2], (name, n, 'drift')
+    dt = time.perf_counter() - t0
+    a, s, it = pl.plan(pb['state'], seed=11, call=7)
+    assert np.array_equal(a, ref[0]) and s == ref[1], (name, 'drift at end')
+    free1 = torch.cuda.mem_get_info()[0]
+    pl.close()
+    print('%-34s %6d plans in %5.1f s (%.3f ms per plan), device memory delta %+d KiB' % (name, n, dt, 1e3 * dt / n, (free0 - free1) // 1024), flush=True)
+    assert free0 - free1 < (8 << 20), 'device memory shrank by more than 8 MiB during the leg'
+
+
+pb = hp.make_problem(60, 2, 5, 4, seed=1)
+_, cfg = hp.configs(pb, N=2000, H=30, P=5, E=5, k=200, I=5, use_graph=True)
+leg('B2 cem (floating segments, graph)', pb, cfg)
+_, cfg = hp.configs(pb, N=2000, H=30, P=5, E=5, k=200, I=5, variant='safe', post=0.3, use_graph=True)
+leg('B2 safe', pb, cfg)
+_, cfg = hp.configs(pb, N=2000, H=30, P=5, E=5, k=200, I=5, use_graph=True)
+leg('B2 cem, weights re-staged / 500', pb, cfg, restage_every=500)
+pbw = hp.make_problem(60, 2, 5, 4, seed=1, units=192, activation='tanh')
+_, cfg = hp.configs(pbw, N=1000, H=20, P=5, E=5, k=100, I=4, use_graph=True)
+leg('generic kernel: 192 units, tanh', pbw, cfg)
+_, cfg = hp.configs(pb, N=24576, H=10, P=5, E=5, k=2457, I=3, use_graph=True)
+leg('fused multi-workgroup select', pb, cfg)
+print('soak ok')
