@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-CEM_ABI_VERSION = 3
+CEM_ABI_VERSION = 4
 CEM_MAX_ACT = 32
 CEM_MAX_COST_KINDS = 4
 CEM_COMM_ID_BYTES = 128
@@ -52,7 +52,7 @@ class CemConfig(C.Structure):
         ('act_mu0', C.c_float * CEM_MAX_ACT), ('act_sigma0', C.c_float * CEM_MAX_ACT),
         ('scorer', CemScorer),
         ('world_size', C.c_int32), ('rank', C.c_int32), ('chunks_per_tile', C.c_int32), ('use_graph', C.c_int32),
-        ('select_mode', C.c_int32), ('rollout_segments', C.c_int32),
+        ('select_mode', C.c_int32), ('rollout_segments', C.c_int32), ('precision', C.c_int32),
     ]
 
 

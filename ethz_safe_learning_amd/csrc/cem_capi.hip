@@ -3,6 +3,7 @@
 #include "cem_device.h"
 #include "cem_train.h"
 #include "cem_train_tile.h"
+#include "cem_rollout_split.h"
 #include "cem_rollout_wide.h"
 #include "../../include/cem_mpc.h"
 
@@ -29,6 +30,7 @@ struct Dims {
     int KB_in, KB_obs, NFW, KF0;     // KF0 = 4*NFW: layer-0 groups per wave, zero padded so every stage is a multiple of 4
     int act_q0, act_nq;              // feature quads of the network input that hold action features: [act_q0, act_q0 + act_nq)
     bool wide;                       // units > 128: the width-generic rollout kernel on the natural weight blob (cem_rollout_wide.h)
+    bool split;                      // precision CEM_PRECISION_SPLIT_BF16X3: cem_rollout_split.h (weight stream in 6 KB chunk groups)
     int wave_groups[4]; uint32_t wave_off_f4[4]; uint32_t member_stride_f4;
     size_t nat_member_floats;
 };
@@ -75,6 +77,8 @@ int validate(const cem_config_t *c)
     if (c->chunks_per_tile < 0 || c->chunks_per_tile > 4) return CEM_ERR_INVALID_ARG;
     if (c->rollout_segments < 0 || c->rollout_segments > 64) return CEM_ERR_INVALID_ARG;
     if (c->select_mode < 0 || c->select_mode > 3) return CEM_ERR_INVALID_ARG;
+    if (c->precision != CEM_PRECISION_FP32 && c->precision != CEM_PRECISION_SPLIT_BF16X3) return CEM_ERR_INVALID_ARG;
+    if (c->precision == CEM_PRECISION_SPLIT_BF16X3 && (c->units > CEM_U || c->activation != CEM_ACT_RELU)) return CEM_ERR_UNSUPPORTED;
     if ((long long)c->particles * c->n_samples > (1ll << 30)) return CEM_ERR_UNSUPPORTED;
     return CEM_OK;
 }
@@ -89,11 +93,14 @@ Dims make_dims(const cem_config_t *c)
     d.KB_in = (d.Din + 15) / 16; d.KB_obs = (d.O + 15) / 16; d.NFW = (d.KB_in + 3) / 4; d.KF0 = 4 * d.NFW;
     d.act_q0 = d.O / 4; d.act_nq = (d.Din + 3) / 4 - d.act_q0;
     d.wide = d.U > CEM_U || c->activation != CEM_ACT_RELU || std::getenv("CEM_FORCE_GENERIC_ROLLOUT") != nullptr;   // (the variable: a diagnostic, scripts/sweep_configs.py)   // the tuned kernels: units <= 128 and relu; everything else takes the generic rollout kernel
+    d.split = !d.wide && c->precision == CEM_PRECISION_SPLIT_BF16X3;
     uint32_t off = 0;
     for (int w = 0; w < 4; ++w) {
-        int g = d.KF0 + CEM_NG * (d.L - 1);
-        for (int i = 0; i < d.NFW; ++i) if (w + 4 * i < d.KB_obs) g += CEM_NG;
-        d.wave_groups[w] = g; d.wave_off_f4[w] = off; off += (uint32_t)g * 128u;
+        // fp32 stream: 2 KB groups, one per 16-feature input block; split stream: 6 KB groups, one per K = 32 chunk (two blocks)
+        const int per_stage = d.split ? CEM_SPLIT_CHUNKS : CEM_NG;
+        int g = (d.split ? 2 * d.NFW : d.KF0) + per_stage * (d.L - 1);
+        for (int i = 0; i < d.NFW; ++i) if (w + 4 * i < d.KB_obs) g += per_stage;
+        d.wave_groups[w] = g; d.wave_off_f4[w] = off; off += (uint32_t)g * (d.split ? 384u : 128u);
     }
     d.member_stride_f4 = off + 256u;    // +2 groups of slack: the prefetch queue may run ahead of a short stream
     d.nat_member_floats = (size_t)d.Din * d.U + d.U + (size_t)(d.L - 1) * ((size_t)d.U * d.U + d.U) + 2 * ((size_t)d.U * d.O + d.O);
@@ -148,6 +155,49 @@ void pack_member(const Dims &d, const float *nat, float *out)
                 const int F = cem_perm_hidden(w, P), Fb = cem_perm_hidden(w, P < 2 ? (P ^ 1) : P);
                 emit(nat + no.Wmu, d.U, d.O, d.O, F, 0, Fo); emit(nat + no.Wvar, d.U, d.O, d.O, Fb, 1, Fo);
                 dst += 512;
+            }
+        }
+    }
+}
+
+// Weight stream of (member, wave) for cem_rollout_split.h: groups of 6 KB in visiting order, one per K = 32 chunk (input blocks
+// 2F, 2F + 1): [a planes 0..2][b planes 0..2], a plane = [64 lanes][8 bf16].  Lane 16 q + i holds, for output feature 16 G + i, the
+// chunk's k slots s = 0..7 = input features 16 (2F + s / 4) + 4 q + s % 4 — what a lane's two accumulator quads of the producing
+// stage hold — as piece `plane` of the exact three-way bf16 split of the weight (cem_split3_bits).
+void pack_member_split(const Dims &d, const float *nat, uint16_t *out)
+{
+    const NatOff no = nat_offsets(d);
+    std::memset(out, 0, (size_t)d.member_stride_f4 * 16);
+    for (int w = 0; w < 4; ++w) {
+        uint16_t *dst = out + (size_t)d.wave_off_f4[w] * 8;
+        auto emit = [&](const float *W, int in_dim, int out_dim, int ld, int F, int ab, int Gout) {
+            for (int lane = 0; lane < 64; ++lane) {
+                const int kq = lane >> 4, i = lane & 15;
+                for (int s = 0; s < 8; ++s) {
+                    const int k = 16 * (2 * F + (s >> 2)) + 4 * kq + (s & 3), o = 16 * Gout + i;
+                    const float v = (k < in_dim && o < out_dim) ? W[(size_t)k * ld + o] : 0.f;
+                    unsigned a[3]; cem_split3_bits(v, a[0], a[1], a[2]);
+                    for (int pl = 0; pl < 3; ++pl) dst[((size_t)(ab * 3 + pl) * 64 + lane) * 8 + s] = (uint16_t)(a[pl] >> 16);
+                }
+            }
+        };
+        for (int P = 0; P < 2 * d.NFW; ++P) {                     // layer 0: chunks in ascending order (no own chunk)
+            emit(nat + no.W[0], d.Din, d.U, d.U, P, 0, 2 * w); emit(nat + no.W[0], d.Din, d.U, d.U, P, 1, 2 * w + 1);
+            dst += 3072;
+        }
+        for (int l = 1; l < d.L; ++l)
+            for (int P = 0; P < CEM_SPLIT_CHUNKS; ++P) {
+                const int F = cem_split_perm(w, P);
+                emit(nat + no.W[l], d.U, d.U, d.U, F, 0, 2 * w); emit(nat + no.W[l], d.U, d.U, d.U, F, 1, 2 * w + 1);
+                dst += 3072;
+            }
+        for (int i = 0; i < d.NFW; ++i) {
+            const int Fo = w + 4 * i;
+            if (Fo >= d.KB_obs) continue;
+            for (int P = 0; P < CEM_SPLIT_CHUNKS; ++P) {          // heads: a = mean, b = variance of observation block Fo
+                const int F = cem_split_perm(w, P);
+                emit(nat + no.Wmu, d.U, d.O, d.O, F, 0, Fo); emit(nat + no.Wvar, d.U, d.O, d.O, F, 1, Fo);
+                dst += 3072;
             }
         }
     }
@@ -369,9 +419,10 @@ Plan make_plan(const cem_config_t *c, const Dims &d)
 {
     Plan pl{};
     pl.rc = d.wide ? 1 : (c->chunks_per_tile ? c->chunks_per_tile : auto_chunks(d, c->rollout_segments));   // the wide kernel: 16-row tiles
+    if (d.split) pl.rc = std::min(pl.rc, 2);            // the split kernel: one or two chunks per tile, whole-horizon tiles (first version)
     std::vector<Tile6> t; build_plan_tiles(d, pl.rc, t);
     pl.n_tiles = (int)t.size();
-    pl.n_seg = d.wide ? 1 : segments_for(d, pl.rc, t.size(), c->rollout_segments);
+    pl.n_seg = (d.wide || d.split) ? 1 : segments_for(d, pl.rc, t.size(), c->rollout_segments);
     pl.seg_len = (d.H + pl.n_seg - 1) / pl.n_seg;
     pl.n_seg = (d.H + pl.seg_len - 1) / pl.seg_len;
     // tiles every CU gets the same number of stay whole ("pinned"); only the remainder floats in segments
@@ -750,7 +801,8 @@ int cem_planner_set_weights(cem_planner_t *h, const float *blob, size_t n_floats
     const NatOff no = nat_offsets(d);
     for (int m = 0; m < d.E; ++m) {
         const float *nat = blob + (size_t)m * d.nat_member_floats;
-        pack_member(d, nat, packed.data() + (size_t)m * d.member_stride_f4 * 4);
+        if (d.split) pack_member_split(d, nat, reinterpret_cast<uint16_t *>(packed.data() + (size_t)m * d.member_stride_f4 * 4));
+        else pack_member(d, nat, packed.data() + (size_t)m * d.member_stride_f4 * 4);
         for (int l = 0; l < d.L; ++l) std::memcpy(&bh[((size_t)m * d.L + l) * CEM_U], nat + no.b[l], d.U * 4);
         std::memcpy(&bmu[(size_t)m * CEM_U], nat + no.bmu, d.O * 4);
         std::memcpy(&bvar[(size_t)m * CEM_U], nat + no.bvar, d.O * 4);
@@ -843,6 +895,23 @@ hipError_t launch_rollout(int rc, int nfw, const RolloutParams &p, int n_tiles, 
     return hipErrorInvalidValue;
 }
 
+// the split-product rollout (cem_rollout_split.h): rc 1 / 2, whole-horizon tiles; mode 1 = caller-supplied noise tensors
+template <int RC, int NFW, int MODE>
+hipError_t launch_rollout_split_t(const RolloutParams &p, int n_tiles, hipStream_t st)
+{
+    const size_t lds = (size_t)2 * CEM_SPLIT_XB(RC) + CEM_PART_FLOATS * 4;
+    hipLaunchKernelGGL((cem_rollout_split_kernel<RC, NFW, MODE>), dim3(n_tiles), dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+hipError_t launch_rollout_split(int rc, int nfw, int mode, const RolloutParams &p, int n_tiles, hipStream_t st)
+{
+#define CEM_CASE(R, F, M) if (rc == R && nfw == F && mode == M) return launch_rollout_split_t<R, F, M>(p, n_tiles, st);
+    CEM_CASE(1, 1, 0) CEM_CASE(2, 1, 0) CEM_CASE(1, 2, 0) CEM_CASE(2, 2, 0)
+    CEM_CASE(1, 1, 1) CEM_CASE(2, 1, 1) CEM_CASE(1, 2, 1) CEM_CASE(2, 2, 1)
+#undef CEM_CASE
+    return hipErrorInvalidValue;
+}
+
 // mode 0: planning; mode 1: caller-supplied action / noise tensors, trajectory and head-moment outputs
 hipError_t launch_rollout_wide(const cem_planner *h, const RolloutParams &rp, int n_tiles, int mode)
 {
@@ -912,6 +981,7 @@ int enqueue_rollout(cem_planner *h, int it)
     size_t e0 = 0;
     if (h->timing) { e0 = h->ev_kind.size() * 2; h->ev_kind.push_back({(int)e0, 0}); hipEventRecord(get_event(h, e0), h->stream); }
     if (d.wide) HIPCHK(launch_rollout_wide(h, rp, h->n_tiles, rp.eps_model ? 1 : 0));
+    else if (d.split) HIPCHK(launch_rollout_split(h->rc, d.NFW, rp.eps_model ? 1 : 0, rp, h->n_tiles, h->stream));
     else if (rp.eps_model) HIPCHK(launch_rollout<1>(h->rc, d.NFW, rp, h->n_tiles, h->stream));
     else if (queued) {
         rp.seg_queue = sp.seg_queue; rp.seg_flags = sp.seg_flags; rp.seg_state = (f4 *)(ws + l.seg_state);
@@ -1233,6 +1303,7 @@ int cem_unfold_sequences(cem_planner_t *h, const float *s0_dev, const float *act
     if (h->in_plan) return CEM_ERR_STATE;
     const Dims &d = h->d;
     if (n_rows % d.E != 0) return CEM_ERR_SPLIT;
+    if (d.split) return CEM_ERR_UNSUPPORTED;            // the weight stream of a split-precision handle is not the fp32 kernels' (cem_mpc.h)
     if ((long long)n_rows * (horizon + 1) * d.O > 0x7fffffff00ll) return CEM_ERR_UNSUPPORTED;
     const int chunk = n_rows / d.E;
     const int rc = d.wide ? 1 : (n_rows >= 256 * 64 ? 4 : (n_rows >= 256 * 32 ? 2 : 1));

@@ -1,0 +1,357 @@
+// cem_rollout_split.h — the rollout with every fp32 product formed on the bf16 matrix pipe from EXACT three-way splits
+// (config field `precision` = CEM_PRECISION_SPLIT_BF16X3; opt-in, never the default).
+//
+// An fp32 number is the exact sum of three bf16 numbers, x = x0 + x1 + x2 (8 significand bits each, truncation split: x0 = the top
+// half of x's bit pattern, x1 = the top half of x - x0, x2 = x - x0 - x1).  A product w * x is then the sum of nine bf16 x bf16
+// products, each exact in the fp32 accumulator of v_mfma_f32_16x16x32_bf16; the six with i + j <= 2 carry everything down to
+// 2^-24 of the product — what an fp32 FMA keeps — and the other three are dropped.  Six bf16 MFMAs of K = 32 replace eight fp32
+// MFMAs of K = 4 per (two input blocks x one output block): 96 matrix-pipe cycles instead of 256, and VALU work issues beside bf16
+// MFMAs instead of taking their slots.  Not bit-identical to the fp32 kernels (the products are summed inside the MFMA, 32 at a
+// time), same error scale; parity is measured against the same oracle at the same tolerances (tests/test_gpu_split.py).
+//
+// Structure: cem_rollout_tile's — 4 waves per tile of 16 RC rows of one member for the whole horizon, wave w computes output blocks
+// 2w, 2w + 1 of a hidden layer and keeps them, SPLIT, as its own K = 32 input chunk of the next stage; the other chunks travel through
+// LDS as three bf16 planes; weights stream from a per-wave image of 6 KB groups (chunk x {a, b} output block x 3 planes) in visiting
+// order.  The epilogue, scorer terms and bookkeeping are cem_rollout_tile's own macros.  First version: whole-horizon tiles only
+// (no floating segments), RC <= 2.
+#pragma once
+#include "cem_device.h"
+
+typedef __bf16 cem_bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned int cem_u2 __attribute__((ext_vector_type(2)));
+#define CEM_MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cem_bf8, (a)), __builtin_bit_cast(cem_bf8, (b)), (c), 0, 0, 0)
+#define CEM_SPLIT_CHUNKS 4                   // K = 32 chunks of a 128-feature layer
+
+// x -> (x0, x1, x2) as bit patterns whose upper halves are the bf16 pieces (host and device: the same operations)
+__host__ __device__ inline void cem_split3_bits(const float x, unsigned &a0, unsigned &a1, unsigned &a2)
+{
+    union { float f; unsigned u; } v, r1, r2, t;
+    v.f = x; a0 = v.u & 0xFFFF0000u;
+    t.u = a0; r1.f = x - t.f; a1 = r1.u & 0xFFFF0000u;
+    t.u = a1; r2.f = r1.f - t.f; a2 = r2.u;
+}
+
+// 8 values (two accumulator quads: features 4q..4q+3 of two 16-feature blocks) -> three planes of 8 bf16
+__device__ __forceinline__ void cem_split8(const f4 x0, const f4 x1, cem_u4 (&p)[3])
+{
+    const float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+    unsigned a0[8], a1[8], a2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a0[i] = __float_as_uint(v[i]) & 0xFFFF0000u;
+        const float r1 = v[i] - __uint_as_float(a0[i]);
+        a1[i] = __float_as_uint(r1) & 0xFFFF0000u;
+        a2[i] = __float_as_uint(r1 - __uint_as_float(a1[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        p[0][i] = __builtin_amdgcn_perm(a0[2 * i + 1], a0[2 * i], 0x07060302u);     // the upper halves of two words -> one word
+        p[1][i] = __builtin_amdgcn_perm(a1[2 * i + 1], a1[2 * i], 0x07060302u);
+        p[2][i] = __builtin_amdgcn_perm(a2[2 * i + 1], a2[2 * i], 0x07060302u);
+    }
+}
+// 4 values (one feature quad of one block) -> three planes of 4 bf16
+__device__ __forceinline__ void cem_split4(const f4 x, cem_u2 (&p)[3])
+{
+    unsigned a0[4], a1[4], a2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a0[i] = __float_as_uint(x[i]) & 0xFFFF0000u;
+        const float r1 = x[i] - __uint_as_float(a0[i]);
+        a1[i] = __float_as_uint(r1) & 0xFFFF0000u;
+        a2[i] = __float_as_uint(r1 - __uint_as_float(a1[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        p[0][i] = __builtin_amdgcn_perm(a0[2 * i + 1], a0[2 * i], 0x07060302u);
+        p[1][i] = __builtin_amdgcn_perm(a1[2 * i + 1], a1[2 * i], 0x07060302u);
+        p[2][i] = __builtin_amdgcn_perm(a2[2 * i + 1], a2[2 * i], 0x07060302u);
+    }
+}
+
+// chunk visited at position phi of a hidden / heads stage by wave w: its own chunk (blocks 2w, 2w + 1) first, the others ascending
+__host__ __device__ inline int cem_split_perm(int w, int phi) { return phi == 0 ? w : (phi - 1 < w ? phi - 1 : phi); }
+
+// LDS: [2 buffers][RC][4 chunks][3 planes][64 lanes][16 B]; a lane's 16 bytes = 4 bf16 of block 2c, 4 bf16 of block 2c + 1
+#define CEM_SPLIT_XB(RC_) ((RC_) * CEM_SPLIT_CHUNKS * 3 * 1024)
+__device__ __forceinline__ int cem_split_off(const int c_rc, const int chunk, const int plane, const int lane)
+{
+    return (((c_rc * CEM_SPLIT_CHUNKS + chunk) * 3 + plane) * 64 + lane) * 16;
+}
+
+// Weight ring over the wave's stream of 6 KB groups: [a planes 0..2][b planes 0..2], a plane = [64 lanes][8 bf16].  Two slots: the
+// group of chunk phi + 1 is requested before the MFMAs of chunk phi (every stage has an even number of chunks).
+struct SRing {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff, n, pos;
+    cem_u4 slot[2][6];
+    __device__ __forceinline__ void ld(cem_u4 (&s)[6], const int g) const
+    {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, g * 6144 + i * 1024, 0);
+    }
+    __device__ __forceinline__ void init(const f4 *b, const int lane_, const int n_)
+    {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f4 *>(b), 0, n_ * 6144, 0x00020000);
+        voff = lane_ * 16; n = n_;
+        ld(slot[0], 0);
+        pos = 1 % n_;
+    }
+};
+
+// One dense stage: acc{0,1}[c] += sum over the stage's chunks of the six split products.  OWN: chunk 0 of the visiting order is the
+// wave's own (planes in registers) and the barrier that publishes the other waves' chunks comes after its MFMAs.  XMODE as in
+// cem_mfma_stage (exchange: barrier inside; re-read: the input was published and waited for by an earlier stage).
+template <int RC, int NCH, bool OWN, int XMODE>
+__device__ __forceinline__ void cem_split_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], const cem_u4 (&own)[RC][3], SRing &wq, const char *smem, const int xr,
+                                                const int lane, const int w)
+{
+    static_assert(NCH % 2 == 0, "stage lengths must keep the ring phase");
+    cem_u4 bp[2][RC][3];                                   // B planes of the chunk in use and of the next one
+#pragma unroll
+    for (int P = 0; P < NCH; ++P) {
+        wq.ld(wq.slot[(P + 1) & 1], wq.pos);               // next chunk's weights (or the next stage's first)
+        wq.pos = (wq.pos + 1 == wq.n) ? 0 : wq.pos + 1;
+        __builtin_amdgcn_sched_barrier(0);
+        if (XMODE == CEM_X_EXCHANGE && P == (OWN ? 1 : 0)) __syncthreads();
+        // activation planes from LDS: the first chunk that is not in registers right after the barrier, every later one a chunk ahead
+        constexpr int FL = OWN ? 1 : 0;
+#pragma unroll
+        for (int Q = P; Q <= P + 1 && Q < NCH; ++Q) {
+            if ((Q == P && P == FL) || (Q == P + 1 && Q > FL)) {
+                const int F = OWN ? cem_split_perm(w, Q) : Q;
+#pragma unroll
+                for (int c = 0; c < RC; ++c)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) bp[Q & 1][c][j] = *reinterpret_cast<const cem_u4 *>(smem + xr + cem_split_off(c, F, j, lane));
+            }
+        }
+        const cem_u4 (&g)[6] = wq.slot[P & 1];
+#pragma unroll
+        for (int c = 0; c < RC; ++c) {
+            const cem_u4 b0 = (OWN && P == 0) ? own[c][0] : bp[P & 1][c][0];
+            const cem_u4 b1 = (OWN && P == 0) ? own[c][1] : bp[P & 1][c][1];
+            const cem_u4 b2 = (OWN && P == 0) ? own[c][2] : bp[P & 1][c][2];
+            // smallest terms first: (2,0) (1,1) (0,2) | (1,0) (0,1) | (0,0)   (weight plane, activation plane)
+            acc0[c] = CEM_MFMA_BF(g[2], b0, acc0[c]); acc1[c] = CEM_MFMA_BF(g[5], b0, acc1[c]);
+            acc0[c] = CEM_MFMA_BF(g[1], b1, acc0[c]); acc1[c] = CEM_MFMA_BF(g[4], b1, acc1[c]);
+            acc0[c] = CEM_MFMA_BF(g[0], b2, acc0[c]); acc1[c] = CEM_MFMA_BF(g[3], b2, acc1[c]);
+            acc0[c] = CEM_MFMA_BF(g[1], b0, acc0[c]); acc1[c] = CEM_MFMA_BF(g[4], b0, acc1[c]);
+            acc0[c] = CEM_MFMA_BF(g[0], b1, acc0[c]); acc1[c] = CEM_MFMA_BF(g[3], b1, acc1[c]);
+            acc0[c] = CEM_MFMA_BF(g[0], b0, acc0[c]); acc1[c] = CEM_MFMA_BF(g[3], b0, acc1[c]);
+        }
+    }
+}
+
+// One tile for the whole horizon (cem_rollout_tile with the split stages; MODE as there)
+template <int RC, int NFW, int MODE>
+__device__ __forceinline__ void cem_rollout_tile_split(const RolloutParams &p, char *smem, const int tile_idx)
+{
+    const int tid = (int)((threadIdx.x + 64u * (unsigned)((tile_idx + (tile_idx >> 8)) & 3)) & 255u);   // wave roles rotate with the tile
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const TileDesc td = p.tiles[tile_idx];
+    const int wbk = 0;
+    const int O = p.O, A = p.A, H = p.H;
+    constexpr int XB = CEM_SPLIT_XB(RC);
+    constexpr int NCH0 = 2 * NFW;                         // K = 32 chunks of the layer-0 input
+    float *part = reinterpret_cast<float *>(smem + 2 * XB);
+    int xw = 0;
+    const PhiloxKey key = cem_key(p.ctrl);
+    const float rscale = p.sampling ? CEM_BM_RSCALE : 0.0f;
+    const int member_u = __builtin_amdgcn_readfirstlane(td.member);
+    SRing wq;
+    wq.init(p.wpack + (size_t)member_u * p.member_stride_f4 + p.wave_off_f4[w], lane, (int)p.wave_groups[w]);
+    const __amdgpu_buffer_rsrc_t et_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.etab + (size_t)member_u * (CEM_ET_ROWS + p.L) * CEM_U), 0, (CEM_ET_ROWS + p.L) * CEM_U * 4, 0x00020000);
+    const int tab_v = 64 * w + 16 * q;
+    const int bias_v = 128 * w + 16 * q;
+
+    f4 s[NFW][RC];
+    int slotc[RC];
+#pragma unroll
+    for (int c = 0; c < RC; ++c) { const int sl = 16 * c + j; slotc[c] = sl < td.cnt ? sl : td.cnt - 1; }
+#pragma unroll
+    for (int i = 0; i < NFW; ++i) {
+        const int f0 = 16 * (w + 4 * i) + 4 * q;
+#pragma unroll
+        for (int c = 0; c < RC; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = f0 + r;
+                float v = 0.f;
+                if (f < O) v = td.s0_base < 0 ? p.ctrl->state[f] : p.s0[(size_t)(td.s0_base + slotc[c]) * O + f];
+                s[i][c][r] = v;
+            }
+    }
+    const __amdgpu_buffer_rsrc_t act_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<f4 *>(p.act_pad), 0, MODE == 0 ? p.act_pad_bytes : 0u, 0x00020000);
+    int actv[NFW][RC];
+    const float *actrow[RC];
+#pragma unroll
+    for (int c = 0; c < RC; ++c) {
+        actrow[c] = p.actions + (size_t)(td.act_base + slotc[c]) * H * A;
+#pragma unroll
+        for (int i = 0; i < NFW; ++i) {
+            int qi = 4 * (w + 4 * i) + q - p.act_q0;
+            qi = qi < 0 ? 0 : (qi >= p.act_nq ? p.act_nq - 1 : qi);
+            actv[i][c] = ((td.act_base + slotc[c]) * H * p.act_nq + qi) * 16;
+        }
+    }
+#define CEM_LOAD_ACT(DST, I_, C_, TN_) do { \
+        if (MODE == 0) DST = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(act_rs, actv[I_][C_], (TN_) * p.act_nq * 16, 0)); \
+        else { _Pragma("unroll") for (int r = 0; r < 4; ++r) { \
+            int af = 16 * (w + 4 * (I_)) + 4 * q + r - O; af = af < 0 ? 0 : (af >= A ? A - 1 : af); \
+            DST[r] = actrow[C_][(TN_) * A + af]; } } } while (0)
+    // the scaled input block Fo of chunk c_rc goes to LDS as three planes of 4 bf16 per lane (its half of the lane's 16 bytes)
+#define CEM_PUBLISH_X(X_, FO_, C_) do { cem_u2 px_[3]; cem_split4((X_), px_); \
+        _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_) \
+            *reinterpret_cast<cem_u2 *>(smem + xw + cem_split_off((C_), (FO_) >> 1, j_, lane) + 8 * ((FO_) & 1)) = px_[j_]; } while (0)
+
+    float d_prev = 0.f, c_prev = 0.f, cum = 0.f;
+    bool done = false;
+    const int nk = 1 + p.sc.n_cost;
+    const float csz[4] = {p.sc.cost_size[0], p.sc.cost_size[1], p.sc.cost_size[2], p.sc.cost_size[3]};
+    const float ind_cap = p.sc.indicator ? 1.0f : __builtin_inff(), clipv = p.sc.reward_clip > 0.f ? p.sc.reward_clip : __builtin_inff();
+    const __amdgpu_buffer_rsrc_t cost_rs = __builtin_amdgcn_make_buffer_rsrc(p.costs, 0, p.costs ? (uint32_t)(H * p.Bloc) : 0u, 0x00020000);
+
+    // ---- prologue: x_0 = scale(concat[s_0, a_0]) and the scorer terms of s_0 --------------------------------------------------
+    {
+        float pm[2][RC];
+#pragma unroll
+        for (int c = 0; c < RC; ++c) { pm[0][c] = __builtin_inff(); pm[1][c] = __builtin_inff(); }
+#pragma unroll
+        for (int i = 0; i < NFW; ++i) {
+            const int tv = tab_v + 256 * i;
+            const f4 mn4 = cem_ld_tab(et_rs, tv, CEM_ET_NMIN * 512), rd4 = cem_ld_tab(et_rs, tv, CEM_ET_RDELTA * 512);
+            const f4 isact4 = cem_ld_tab(et_rs, tv, CEM_ET_ACT * 512);
+            const f4 sel0 = cem_ld_tab(et_rs, tv, CEM_ET_SEL0 * 512), sel1 = cem_ld_tab(et_rs, tv, CEM_ET_SEL1 * 512);
+#pragma unroll
+            for (int c = 0; c < RC; ++c) {
+                f4 act4; CEM_LOAD_ACT(act4, i, c, 0);
+                const f4 sn = s[i][c];
+                cem_scorer_terms(sn, p.sc.D, sel0, sel1, pm[0][c], pm[1][c]);
+                const f4 x = cem_sub4(__builtin_elementwise_fma(isact4, act4, sn), mn4) * rd4;
+                CEM_PUBLISH_X(x, w + 4 * i, c);
+            }
+        }
+        CEM_RARE_KINDS_AND_STORE();
+        xw = XB;
+    }
+    f4 nb0 = cem_ld_tab(et_rs, bias_v, CEM_ET_ROWS * 512);
+    f4 nb1 = cem_ld_tab(et_rs, bias_v + 64, CEM_ET_ROWS * 512);
+    cem_u4 own[RC][3];                                    // the wave's own chunk (its two output blocks of the last hidden stage), split
+#pragma unroll
+    for (int c = 0; c < RC; ++c)
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) own[c][jj] = (cem_u4){0u, 0u, 0u, 0u};
+
+    const int prio_r0 = (tile_idx >> 8) % 3;
+    for (int t = 0; t < H; ++t) {
+        {
+            const int lvl = (t + prio_r0) % 3;
+            if (lvl == 0) __builtin_amdgcn_s_setprio(0); else if (lvl == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
+        }
+#define CEM_SPLIT_PUBLISH() do { \
+            _Pragma("unroll") for (int c = 0; c < RC; ++c) { \
+                f4 h0 = acc0[c], h1 = acc1[c]; \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) { h0[r] = fmaxf(h0[r], 0.f); h1[r] = fmaxf(h1[r], 0.f); } \
+                cem_split8(h0, h1, own[c]); \
+                _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_) *reinterpret_cast<cem_u4 *>(smem + xw + cem_split_off(c, w, j_, lane)) = own[c][j_]; \
+            } \
+            xw ^= XB; } while (0)
+#define CEM_NEXT_BIAS(LN) do { \
+            nb0 = cem_ld_tab(et_rs, bias_v, (CEM_ET_ROWS + (LN)) * 512); \
+            nb1 = cem_ld_tab(et_rs, bias_v + 64, (CEM_ET_ROWS + (LN)) * 512); } while (0)
+        {
+            f4 acc0[RC], acc1[RC];
+#pragma unroll
+            for (int c = 0; c < RC; ++c) { acc0[c] = nb0; acc1[c] = nb1; }
+            CEM_NEXT_BIAS(p.L > 1 ? 1 : 0);
+            // layer 0: every chunk of the scaled input comes from LDS (a wave's input blocks w, w + 4 are halves of two chunks)
+            cem_split_stage<RC, NCH0, false, CEM_X_EXCHANGE>(acc0, acc1, own, wq, smem, xw ^ XB, lane, w);
+            CEM_BOOKKEEP(t - 1);
+            CEM_SPLIT_PUBLISH();
+        }
+        for (int l = 1; l < p.L; ++l) {
+            f4 acc0[RC], acc1[RC];
+#pragma unroll
+            for (int c = 0; c < RC; ++c) { acc0[c] = nb0; acc1[c] = nb1; }
+            CEM_NEXT_BIAS(l + 1 < p.L ? l + 1 : 0);
+            cem_split_stage<RC, CEM_SPLIT_CHUNKS, true, CEM_X_EXCHANGE>(acc0, acc1, own, wq, smem, xw ^ XB, lane, w);
+            CEM_SPLIT_PUBLISH();
+        }
+#undef CEM_SPLIT_PUBLISH
+#undef CEM_NEXT_BIAS
+
+        // ---- heads, state update, scorer terms, next scaled input: cem_rollout_tile's epilogue ------------------------------------
+        float pm[2][RC];
+#pragma unroll
+        for (int c = 0; c < RC; ++c) { pm[0][c] = __builtin_inff(); pm[1][c] = __builtin_inff(); }
+        const int tn = (t + 1 < H) ? t + 1 : H - 1;
+#pragma unroll
+        for (int i = 0; i < NFW; ++i) {
+            const int Fo = w + 4 * i;
+            const int tv = tab_v + 256 * i;
+            const f4 mn4 = cem_ld_tab(et_rs, tv, CEM_ET_NMIN * 512), rd4 = cem_ld_tab(et_rs, tv, CEM_ET_RDELTA * 512);
+            const f4 bm = cem_ld_tab(et_rs, tv, CEM_ET_BMU * 512), bv = cem_ld_tab(et_rs, tv, CEM_ET_BVAR * 512);
+            const f4 om4 = cem_ld_tab(et_rs, tv, CEM_ET_OBS * 512), isact4 = cem_ld_tab(et_rs, tv, CEM_ET_ACT * 512);
+            const f4 sel0 = cem_ld_tab(et_rs, tv, CEM_ET_SEL0 * 512), sel1 = cem_ld_tab(et_rs, tv, CEM_ET_SEL1 * 512);
+            f4 act4[RC], eps4[RC];
+#pragma unroll
+            for (int c = 0; c < RC; ++c) {
+                CEM_LOAD_ACT(act4[c], i, c, tn);
+                if (MODE == 1 && p.eps_model) {
+                    const int f0 = 16 * Fo + 4 * q;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int fc = (f0 + r < O) ? f0 + r : O - 1;
+                        eps4[c][r] = p.eps_model[((size_t)t * p.Btot + td.noise_row_base + slotc[c]) * O + fc];
+                    }
+                    eps4[c] = eps4[c] * (p.sampling ? 1.0f : 0.0f);
+                } else {
+                    eps4[c] = cem_normal4((uint32_t)(td.noise_row_base + slotc[c]), (uint32_t)t, (uint32_t)p.it,
+                                          (uint32_t)(4 * Fo + q), CEM_STREAM_MODEL, key, rscale);
+                }
+            }
+            f4 accm[RC], accv[RC];
+#pragma unroll
+            for (int c = 0; c < RC; ++c) { accm[c] = bm; accv[c] = bv; }
+            if (Fo < p.KB_obs) {                                                           // wave-uniform
+                if (i == 0) cem_split_stage<RC, CEM_SPLIT_CHUNKS, true, CEM_X_EXCHANGE>(accm, accv, own, wq, smem, xw ^ XB, lane, w);
+                else cem_split_stage<RC, CEM_SPLIT_CHUNKS, true, CEM_X_REREAD>(accm, accv, own, wq, smem, xw ^ XB, lane, w);
+            } else if (i == 0) {
+                __syncthreads();                      // keep the barrier count of waves without observation features
+            }
+#pragma unroll
+            for (int c = 0; c < RC; ++c) {
+                const f4 mu = accm[c];
+                const f4 var = cem_softplus4(accv[c]) + 1e-4f;
+                f4 sd;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sd[r] = __builtin_amdgcn_sqrtf(var[r]);
+                const f4 d = mu + sd * eps4[c];
+                const f4 sn = s[i][c] + d * om4;
+                s[i][c] = sn;
+                cem_scorer_terms(sn, p.sc.D, sel0, sel1, pm[0][c], pm[1][c]);
+                const f4 x = cem_sub4(__builtin_elementwise_fma(isact4, act4[c], sn), mn4) * rd4;
+                CEM_PUBLISH_X(x, Fo, c);
+            }
+        }
+        CEM_RARE_KINDS_AND_STORE();
+        xw ^= XB;
+    }
+    __syncthreads();
+    CEM_BOOKKEEP(H - 1);
+    if (w == wbk && lane < td.cnt) p.ret[td.row_base + lane] = cum;
+#undef CEM_LOAD_ACT
+#undef CEM_PUBLISH_X
+}
+
+template <int RC, int NFW, int MODE>
+__global__ __launch_bounds__(256) void cem_rollout_split_kernel(const RolloutParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.check_done && p.ctrl->done) return;
+    cem_rollout_tile_split<RC, NFW, MODE>(p, smem, (int)blockIdx.x);
+}

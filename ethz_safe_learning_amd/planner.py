@@ -61,6 +61,7 @@ class PlannerConfig:
     chunks_per_tile: int = 0
     use_graph: bool = False
     rollout_segments: int = 0          # 0 auto, 1 off, n > 1: horizon-segment work queue (cem_mpc.h)
+    precision: str = 'fp32'            # 'fp32' | 'bf16x3' (enum cem_precision: exact three-way bf16 split products, opt-in)
     select_mode: int = 0               # 0 auto, 1 one-workgroup select, 2 multi-workgroup chain, 3 the chain fused into one launch (cem_mpc.h)
 
 
@@ -128,6 +129,7 @@ def to_c_config(cfg: PlannerConfig) -> _capi.CemConfig:
         c.scorer.cost_lo[i], c.scorer.cost_hi[i], c.scorer.cost_size[i] = int(lo), int(hi), float(size)
     c.world_size, c.rank, c.chunks_per_tile, c.use_graph = cfg.world_size, cfg.rank, cfg.chunks_per_tile, int(cfg.use_graph)
     c.rollout_segments = int(cfg.rollout_segments)
+    c.precision = {'fp32': 0, 'bf16x3': 1}[cfg.precision]
     c.select_mode = int(cfg.select_mode)
     return c
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CEM_ABI_VERSION 3
+#define CEM_ABI_VERSION 4
 #define CEM_MAX_ACT 32
 #define CEM_MAX_COST_KINDS 4
 
@@ -75,6 +75,13 @@ typedef struct cem_scorer {
     float cost_size[CEM_MAX_COST_KINDS];
 } cem_scorer_t;
 
+/* How the rollout's dense layers multiply.  Both accumulate in fp32 and keep every term of a product down to 2^-24 of it.
+ * CEM_PRECISION_FP32: v_mfma_f32_16x16x4_f32 (the default; what every number in BASELINE / DESIGN is quoted on unless labelled).
+ * CEM_PRECISION_SPLIT_BF16X3: weights and activations as exact three-way bf16 splits, the six leading bf16 x bf16 products per
+ * fp32 product on v_mfma_f32_16x16x32_bf16 (csrc/cem_rollout_split.h).  Same oracle, same tolerances, not bit-identical to the
+ * fp32 form; units <= 128 and relu only; plans only (cem_unfold_sequences returns CEM_ERR_UNSUPPORTED on such a handle). */
+enum cem_precision { CEM_PRECISION_FP32 = 0, CEM_PRECISION_SPLIT_BF16X3 = 1 };
+
 /* Constructor kwargs of CemMpc / SafeCemMpc (cem_mpc.py:7-17, safe_cem_mpc.py:8-19)
  * + the model dims of TransitionModel/MlpEnsemble (transition_model.py:8-21,
  * config/models.yaml) + candidate sharding. */
@@ -117,6 +124,7 @@ typedef struct cem_config {
     int32_t rollout_segments;     /* 0 = auto; 1 = one workgroup per tile for the whole horizon; n > 1 = the rollout launch is a
                                    * work queue of (tile, horizon/n) items drawn by resident workgroups — evens out CU load when the
                                    * tile count is not a multiple of the CU count; results are bit-identical either way */
+    int32_t precision;            /* enum cem_precision: how the rollout forms its fp32 products (ABI 4) */
 } cem_config_t;
 
 /* Byte offsets into the caller's workspace of the arrays a host binding needs

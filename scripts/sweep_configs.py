@@ -18,7 +18,8 @@ for name, O, A, K, N, H in CFG:
         continue
     pb = synthetic.problem(O, A, K)
     cfg = PlannerConfig(obs_dim=O, act_dim=A, ensemble_size=K, particles=K, n_samples=N, horizon=H, n_elite=N // 10, iterations=5,
-                        scorer=pb['scorer'], act_low=pb['low'], act_high=pb['high'], noise_stddev=1e-3, use_graph=not NOGRAPH, chunks_per_tile=CHUNKS)
+                        scorer=pb['scorer'], act_low=pb['low'], act_high=pb['high'], noise_stddev=1e-3, use_graph=not NOGRAPH, chunks_per_tile=CHUNKS,
+                        precision=os.environ.get('CEM_SWEEP_PRECISION', 'fp32'))
     pl = CemPlanner(cfg); pl.set_weights(pb['weights']); pl.set_normaliser(pb['inputs_min'], pb['inputs_max'])
     for i in range(1 if NOGRAPH else (12 if N <= 2000 else 3)):      # small plans: the first ~10 run at ramping clocks (2.6 -> 2.16 ms at B2)
         pl.plan(pb['state'], seed=1, call=i)

@@ -19,7 +19,7 @@ def make_problem(obs_dim=60, act_dim=2, E=5, n_layers=4, seed=1234, bias_noise=0
 
 
 def configs(pb, N, H, P, E, k, I=3, variant='cem', thr=-1.0, noise=0.0, post=0.3, smoothing=0.0,
-            sampling=True, scale=True, world_size=1, rank=0, chunks_per_tile=0, use_graph=False, rollout_segments=0, select_mode=0):
+            sampling=True, scale=True, world_size=1, rank=0, chunks_per_tile=0, use_graph=False, rollout_segments=0, select_mode=0, precision='fp32'):
     sp = pb['scorer']
     O, A = pb['state'].shape[0], pb['low'].shape[0]
     ocfg = o.PlanConfig(horizon=H, iterations=I, n_samples=N, n_elite=k, particles=P, ensemble_size=E, smoothing=smoothing,
@@ -36,7 +36,8 @@ def configs(pb, N, H, P, E, k, I=3, variant='cem', thr=-1.0, noise=0.0, post=0.3
                          smoothing=smoothing,
                          stddev_threshold=thr, noise_stddev=noise, variant=variant, posterior_mean_threashold=post,
                          sampling_propagation=sampling, scale_features=scale, world_size=world_size, rank=rank,
-                         chunks_per_tile=chunks_per_tile, use_graph=use_graph, rollout_segments=rollout_segments, select_mode=select_mode)
+                         chunks_per_tile=chunks_per_tile, use_graph=use_graph, rollout_segments=rollout_segments, select_mode=select_mode,
+                         precision=precision)
     return ocfg, pcfg
 
 

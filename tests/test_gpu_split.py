@@ -1,0 +1,108 @@
+"""The split-product rollout (precision 'bf16x3': csrc/cem_rollout_split.h) against the SAME oracle at the SAME tolerances as the fp32
+kernels, plus the invariances that must hold bit for bit within it (rank shards, tile sizes)."""
+import numpy as np
+import pytest
+
+from oracle import cem_oracle as o
+from tests import helpers as hp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('variant', ['cem', 'safe'])
+@pytest.mark.parametrize('dims', [(60, 2, 128), (100, 12, 128), (23, 3, 48)], ids=['obs60', 'obs100', 'obs23_units48'])
+def test_whole_plan_matches_oracle(variant, dims):
+    O, A, U = dims
+    pb = hp.make_problem(O, A, 5, 4, seed=7 + O, units=U)
+    N, H, P, E, k, I = 128, 8, 5, 5, 12, 3
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, variant=variant, noise=0.01, post=0.3, precision='bf16x3')
+    pl = hp.make_planner(pb, pcfg)
+    ea, em, eo = hp.noise(I, N, H, A, P, O, seed=3)
+    a, s, it = pl.plan(pb['state'], eps_act=ea, eps_model=em, eps_out=eo)
+    ra, rs, rit = o.do_generate_action(pb['state'], pb['weights'], pb['inputs_min'], pb['inputs_max'], pb['low'], pb['high'],
+                                       ea, em, eo, ocfg, pb['scorer'])
+    assert it == rit and abs(s - rs) <= 2e-5, (s, rs)
+    np.testing.assert_allclose(a, ra, rtol=1e-5, atol=1e-6)
+
+
+ATOL = 5e-6                                             # the fp32 kernels' bound (tests/test_gpu_parity.py)
+
+
+def _iteration_scores(pl, pb, ea, em):
+    import torch
+    pl.plan_begin(pb['state'], eps_act=ea, eps_model=em)
+    pl.plan_rollout(0)
+    torch.cuda.synchronize()
+    sc = pl.scores_local().cpu().numpy().copy()
+    pl.plan_end()
+    return sc
+
+
+@pytest.mark.parametrize('variant', ['cem', 'safe'])
+@pytest.mark.parametrize('rc', [1, 2])
+@pytest.mark.parametrize('dims', [(60, 2), (100, 12)], ids=['obs60', 'obs100'])
+def test_scores_match_oracle_and_fp32_kernel(variant, rc, dims):
+    """Per-candidate scores of one iteration on dumped noise: split vs the fp64 oracle at the fp32 kernels' bound (near-threshold
+    candidates under the admissible outcomes), and split vs the fp32 kernel."""
+    O, A = dims
+    pb = hp.make_problem(O, A, 5, 4, seed=21 + O)
+    N, H, P, E, k, I = 256, 12, 5, 5, 25, 1
+    ea, em, eo = hp.noise(I, N, H, A, P, O, seed=5)
+    sc = {}
+    for prec in ('fp32', 'bf16x3'):
+        ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, variant=variant, post=0.3, precision=prec, chunks_per_tile=rc)
+        pl = hp.make_planner(pb, pcfg)
+        sc[prec] = _iteration_scores(pl, pb, ea, em)
+        pl.close()
+    lb, ub, mu0, sg0 = o.sampling_params(pb['low'], pb['high'])
+    ref_actions = o.sample_actions(np.broadcast_to(mu0, (H, A)), np.broadcast_to(sg0, (H, A)), lb, ub, ea[0])
+    ref64, traj64 = o.candidate_scores(pb['state'].astype(np.float64), ref_actions.astype(np.float64), o.cast_weights(pb['weights'], np.float64),
+                                       pb['inputs_min'], pb['inputs_max'], em[0], ocfg, pb['scorer'], return_traj=True)
+    err, n_near, n_flip = hp.assert_scores_match_oracle(sc['bf16x3'], traj64, P, N, pb['scorer'], variant, 0.3, ATOL, 'split rc %d' % rc)
+    err32, _, _ = hp.assert_scores_match_oracle(sc['fp32'], traj64, P, N, pb['scorer'], variant, 0.3, ATOL, 'fp32 rc %d' % rc)
+    d = np.abs(sc['bf16x3'] - sc['fp32'])
+    print('obs %d %s rc %d: max |score - oracle| split %.2e, fp32 kernel %.2e; split vs fp32 kernel: median %.1e max %.1e; %d near a threshold, %d flipped'
+          % (O, variant, rc, err, err32, np.median(d), d.max(), n_near, n_flip))
+
+
+def test_rank_shards_and_tile_sizes_are_bit_identical_within_the_split_kernel():
+    import torch
+    pb = hp.make_problem(60, 2, 5, 4, seed=33)
+    N, H, P, E, k, I = 512, 10, 5, 5, 51, 2
+    ref = None
+    for rc in (1, 2):
+        _, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, precision='bf16x3', chunks_per_tile=rc)
+        pl = hp.make_planner(pb, pcfg)
+        a, s, it = pl.plan(pb['state'], seed=9, call=4)
+        sc = pl.scores_global().cpu().numpy().copy()
+        pl.close()
+        if ref is None:
+            ref = (a, s, sc)
+        else:
+            np.testing.assert_array_equal(sc, ref[2]); np.testing.assert_array_equal(a, ref[0]); assert s == ref[1]
+    # two half-shards, exchanged by hand, reproduce the single-rank scores
+    halves = []
+    for r in range(2):
+        _, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, precision='bf16x3', world_size=2, rank=r)
+        pl = hp.make_planner(pb, pcfg)
+        pl.plan_begin(pb['state'], seed=9, call=4)
+        pl.plan_rollout(0)
+        torch.cuda.synchronize()
+        halves.append(pl.scores_local().cpu().numpy().copy())
+        pl.plan_end()
+        pl.close()
+    _, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=1, precision='bf16x3')
+    pl = hp.make_planner(pb, pcfg)
+    pl.plan(pb['state'], seed=9, call=4)
+    np.testing.assert_array_equal(np.concatenate(halves), pl.scores_global().cpu().numpy())
+    pl.close()
+
+
+def test_unfold_is_refused_on_a_split_handle():
+    import torch
+    pb = hp.make_problem(60, 2, 5, 4, seed=1)
+    _, pcfg = hp.configs(pb, N=64, H=4, P=5, E=5, k=6, I=1, precision='bf16x3')
+    pl = hp.make_planner(pb, pcfg)
+    with pytest.raises(Exception):
+        pl.unfold_sequences(torch.zeros(10, 60), torch.zeros(10, 4, 2))
+    pl.close()
