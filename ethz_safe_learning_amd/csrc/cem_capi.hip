@@ -98,7 +98,7 @@ Dims make_dims(const cem_config_t *c)
     for (int w = 0; w < 4; ++w) {
         // fp32 stream: 2 KB groups, one per 16-feature input block; split stream: 6 KB groups, one per K = 32 chunk (two blocks)
         const int per_stage = d.split ? CEM_SPLIT_CHUNKS : CEM_NG;
-        int g = (d.split ? 2 * d.NFW : d.KF0) + per_stage * (d.L - 1);
+        int g = (d.split ? cem_split_l0_chunks(d.NFW) : d.KF0) + per_stage * (d.L - 1);
         for (int i = 0; i < d.NFW; ++i) if (w + 4 * i < d.KB_obs) g += per_stage;
         d.wave_groups[w] = g; d.wave_off_f4[w] = off; off += (uint32_t)g * (d.split ? 384u : 128u);
     }
@@ -181,7 +181,7 @@ void pack_member_split(const Dims &d, const float *nat, uint16_t *out)
                 }
             }
         };
-        for (int P = 0; P < 2 * d.NFW; ++P) {                     // layer 0: chunks in ascending order (no own chunk)
+        for (int P = 0; P < cem_split_l0_chunks(d.NFW); ++P) {    // layer 0: chunks in ascending order (no own chunk); chunks past the input are zero
             emit(nat + no.W[0], d.Din, d.U, d.U, P, 0, 2 * w); emit(nat + no.W[0], d.Din, d.U, d.U, P, 1, 2 * w + 1);
             dst += 3072;
         }
@@ -419,7 +419,15 @@ Plan make_plan(const cem_config_t *c, const Dims &d)
 {
     Plan pl{};
     pl.rc = d.wide ? 1 : (c->chunks_per_tile ? c->chunks_per_tile : auto_chunks(d, c->rollout_segments));   // the wide kernel: 16-row tiles
-    if (d.split) pl.rc = std::min(pl.rc, 2);            // the split kernel: one or two chunks per tile, whole-horizon tiles (first version)
+    if (d.split && !c->chunks_per_tile) {
+        // The split kernel streams 1.5x the weight bytes at 2.7x the matrix rate: one-chunk tiles are bound by the L2 -> CU path
+        // (64 B per clock per CU: 438 KB per tile-step = 6.8 K cycles against 3.5 K of MFMA), so a tile takes as many chunks as the
+        // population has per CU, up to what keeps two workgroups resident (3 at obs+act <= 64: 218 VGPRs / 77 KB LDS; 2 above:
+        // 229 VGPRs).  Measured (profiles/r03_split_tile_sizes.txt): B1 1, B2 3, B3 3, B4 2, B5 rank 3.
+        std::vector<Tile6> t1; build_plan_tiles(d, 1, t1);
+        const int per_cu = (int)((t1.size() + num_cus() - 1) / num_cus());
+        pl.rc = std::max(1, std::min(per_cu, d.NFW == 1 ? 3 : 2));
+    }
     std::vector<Tile6> t; build_plan_tiles(d, pl.rc, t);
     pl.n_tiles = (int)t.size();
     pl.n_seg = (d.wide || d.split) ? 1 : segments_for(d, pl.rc, t.size(), c->rollout_segments);
@@ -906,8 +914,8 @@ hipError_t launch_rollout_split_t(const RolloutParams &p, int n_tiles, hipStream
 hipError_t launch_rollout_split(int rc, int nfw, int mode, const RolloutParams &p, int n_tiles, hipStream_t st)
 {
 #define CEM_CASE(R, F, M) if (rc == R && nfw == F && mode == M) return launch_rollout_split_t<R, F, M>(p, n_tiles, st);
-    CEM_CASE(1, 1, 0) CEM_CASE(2, 1, 0) CEM_CASE(1, 2, 0) CEM_CASE(2, 2, 0)
-    CEM_CASE(1, 1, 1) CEM_CASE(2, 1, 1) CEM_CASE(1, 2, 1) CEM_CASE(2, 2, 1)
+    CEM_CASE(1, 1, 0) CEM_CASE(2, 1, 0) CEM_CASE(1, 2, 0) CEM_CASE(2, 2, 0) CEM_CASE(3, 1, 0) CEM_CASE(4, 1, 0) CEM_CASE(3, 2, 0) CEM_CASE(4, 2, 0)
+    CEM_CASE(1, 1, 1) CEM_CASE(2, 1, 1) CEM_CASE(1, 2, 1) CEM_CASE(2, 2, 1) CEM_CASE(3, 1, 1) CEM_CASE(4, 1, 1) CEM_CASE(3, 2, 1) CEM_CASE(4, 2, 1)
 #undef CEM_CASE
     return hipErrorInvalidValue;
 }

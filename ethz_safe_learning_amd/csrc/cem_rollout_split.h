@@ -79,12 +79,18 @@ __device__ __forceinline__ int cem_split_off(const int c_rc, const int chunk, co
     return (((c_rc * CEM_SPLIT_CHUNKS + chunk) * 3 + plane) * 64 + lane) * 16;
 }
 
-// Weight ring over the wave's stream of 6 KB groups: [a planes 0..2][b planes 0..2], a plane = [64 lanes][8 bf16].  Two slots: the
-// group of chunk phi + 1 is requested before the MFMAs of chunk phi (every stage has an even number of chunks).
+// Weight ring over the wave's stream of 6 KB groups: [a planes 0..2][b planes 0..2], a plane = [64 lanes][8 bf16].  CEM_SPLIT_RING
+// slots, RING - 1 groups ahead of the MFMAs; every stage is a multiple of RING chunks long, so the slot of a stage's chunk phi is
+// the compile-time constant phi % RING (with RING 4 the two-chunk layer 0 of the obs+act <= 64 family is padded with two
+// zero-weight chunks: cem_split_l0_chunks, host and device).
+#ifndef CEM_SPLIT_RING
+#define CEM_SPLIT_RING 2                       // measured 2 vs 4 (same box): B1 0.123 vs 0.133 ms, B2 0.358 vs 0.510, B3 2.93 vs 3.12, B4 1.60 vs 1.86 (48 more VGPRs cost a resident workgroup)
+#endif
+__host__ __device__ constexpr int cem_split_l0_chunks(int nfw) { return 2 * nfw < CEM_SPLIT_RING ? CEM_SPLIT_RING : 2 * nfw; }
 struct SRing {
     __amdgpu_buffer_rsrc_t rsrc;
     int voff, n, pos;
-    cem_u4 slot[2][6];
+    cem_u4 slot[CEM_SPLIT_RING][6];
     __device__ __forceinline__ void ld(cem_u4 (&s)[6], const int g) const
     {
 #pragma unroll
@@ -94,8 +100,9 @@ struct SRing {
     {
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f4 *>(b), 0, n_ * 6144, 0x00020000);
         voff = lane_ * 16; n = n_;
-        ld(slot[0], 0);
-        pos = 1 % n_;
+#pragma unroll
+        for (int i = 0; i < CEM_SPLIT_RING - 1; ++i) ld(slot[i], i % n_);
+        pos = (CEM_SPLIT_RING - 1) % n_;
     }
 };
 
@@ -106,11 +113,11 @@ template <int RC, int NCH, bool OWN, int XMODE>
 __device__ __forceinline__ void cem_split_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], const cem_u4 (&own)[RC][3], SRing &wq, const char *smem, const int xr,
                                                 const int lane, const int w)
 {
-    static_assert(NCH % 2 == 0, "stage lengths must keep the ring phase");
+    static_assert(NCH % CEM_SPLIT_RING == 0, "stage lengths must keep the ring phase");
     cem_u4 bp[2][RC][3];                                   // B planes of the chunk in use and of the next one
 #pragma unroll
     for (int P = 0; P < NCH; ++P) {
-        wq.ld(wq.slot[(P + 1) & 1], wq.pos);               // next chunk's weights (or the next stage's first)
+        wq.ld(wq.slot[(P + CEM_SPLIT_RING - 1) % CEM_SPLIT_RING], wq.pos);     // the group RING - 1 chunks ahead (possibly the next stage's)
         wq.pos = (wq.pos + 1 == wq.n) ? 0 : wq.pos + 1;
         __builtin_amdgcn_sched_barrier(0);
         if (XMODE == CEM_X_EXCHANGE && P == (OWN ? 1 : 0)) __syncthreads();
@@ -126,7 +133,7 @@ __device__ __forceinline__ void cem_split_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], 
                     for (int j = 0; j < 3; ++j) bp[Q & 1][c][j] = *reinterpret_cast<const cem_u4 *>(smem + xr + cem_split_off(c, F, j, lane));
             }
         }
-        const cem_u4 (&g)[6] = wq.slot[P & 1];
+        const cem_u4 (&g)[6] = wq.slot[P % CEM_SPLIT_RING];
 #pragma unroll
         for (int c = 0; c < RC; ++c) {
             const cem_u4 b0 = (OWN && P == 0) ? own[c][0] : bp[P & 1][c][0];
@@ -155,9 +162,13 @@ __device__ __forceinline__ void cem_rollout_tile_split(const RolloutParams &p, c
     const int wbk = 0;
     const int O = p.O, A = p.A, H = p.H;
     constexpr int XB = CEM_SPLIT_XB(RC);
-    constexpr int NCH0 = 2 * NFW;                         // K = 32 chunks of the layer-0 input
+    constexpr int NCH0 = cem_split_l0_chunks(NFW);        // K = 32 chunks of the layer-0 input (padded to the ring length)
     float *part = reinterpret_cast<float *>(smem + 2 * XB);
     int xw = 0;
+    if (NCH0 > 2 * NFW) {                                 // padded layer-0 chunks meet zero weights: what LDS holds there must be finite
+        for (int o = (int)threadIdx.x * 16; o < 2 * XB; o += 256 * 16) *reinterpret_cast<cem_u4 *>(smem + o) = (cem_u4){0u, 0u, 0u, 0u};
+        __syncthreads();
+    }
     const PhiloxKey key = cem_key(p.ctrl);
     const float rscale = p.sampling ? CEM_BM_RSCALE : 0.0f;
     const int member_u = __builtin_amdgcn_readfirstlane(td.member);
@@ -246,6 +257,11 @@ __device__ __forceinline__ void cem_rollout_tile_split(const RolloutParams &p, c
 #pragma unroll
         for (int jj = 0; jj < 3; ++jj) own[c][jj] = (cem_u4){0u, 0u, 0u, 0u};
 
+#ifdef CEM_STAMPS
+    long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev_ = (long long)__builtin_amdgcn_s_memtime();
+    st_[7] = tprev_;
+#endif
     const int prio_r0 = (tile_idx >> 8) % 3;
     for (int t = 0; t < H; ++t) {
         {
@@ -270,8 +286,11 @@ __device__ __forceinline__ void cem_rollout_tile_split(const RolloutParams &p, c
             CEM_NEXT_BIAS(p.L > 1 ? 1 : 0);
             // layer 0: every chunk of the scaled input comes from LDS (a wave's input blocks w, w + 4 are halves of two chunks)
             cem_split_stage<RC, NCH0, false, CEM_X_EXCHANGE>(acc0, acc1, own, wq, smem, xw ^ XB, lane, w);
+            CEM_STAMP(0);
             CEM_BOOKKEEP(t - 1);
+            CEM_STAMP(6);
             CEM_SPLIT_PUBLISH();
+            CEM_STAMP(5);
         }
         for (int l = 1; l < p.L; ++l) {
             f4 acc0[RC], acc1[RC];
@@ -279,7 +298,9 @@ __device__ __forceinline__ void cem_rollout_tile_split(const RolloutParams &p, c
             for (int c = 0; c < RC; ++c) { acc0[c] = nb0; acc1[c] = nb1; }
             CEM_NEXT_BIAS(l + 1 < p.L ? l + 1 : 0);
             cem_split_stage<RC, CEM_SPLIT_CHUNKS, true, CEM_X_EXCHANGE>(acc0, acc1, own, wq, smem, xw ^ XB, lane, w);
+            CEM_STAMP(1);
             CEM_SPLIT_PUBLISH();
+            CEM_STAMP(5);
         }
 #undef CEM_SPLIT_PUBLISH
 #undef CEM_NEXT_BIAS
@@ -317,12 +338,14 @@ __device__ __forceinline__ void cem_rollout_tile_split(const RolloutParams &p, c
             f4 accm[RC], accv[RC];
 #pragma unroll
             for (int c = 0; c < RC; ++c) { accm[c] = bm; accv[c] = bv; }
+            CEM_STAMP(2);
             if (Fo < p.KB_obs) {                                                           // wave-uniform
                 if (i == 0) cem_split_stage<RC, CEM_SPLIT_CHUNKS, true, CEM_X_EXCHANGE>(accm, accv, own, wq, smem, xw ^ XB, lane, w);
                 else cem_split_stage<RC, CEM_SPLIT_CHUNKS, true, CEM_X_REREAD>(accm, accv, own, wq, smem, xw ^ XB, lane, w);
             } else if (i == 0) {
                 __syncthreads();                      // keep the barrier count of waves without observation features
             }
+            CEM_STAMP(3);
 #pragma unroll
             for (int c = 0; c < RC; ++c) {
                 const f4 mu = accm[c];
@@ -340,10 +363,14 @@ __device__ __forceinline__ void cem_rollout_tile_split(const RolloutParams &p, c
         }
         CEM_RARE_KINDS_AND_STORE();
         xw ^= XB;
+        CEM_STAMP(4);
     }
     __syncthreads();
     CEM_BOOKKEEP(H - 1);
     if (w == wbk && lane < td.cnt) p.ret[td.row_base + lane] = cum;
+#ifdef CEM_STAMPS
+    if (p.stamps && lane == 0) for (int i = 0; i < 8; ++i) p.stamps[((size_t)tile_idx * 4 + w) * 8 + i] = st_[i];
+#endif
 #undef CEM_LOAD_ACT
 #undef CEM_PUBLISH_X
 }

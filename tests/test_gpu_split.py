@@ -39,7 +39,7 @@ def _iteration_scores(pl, pb, ea, em):
 
 
 @pytest.mark.parametrize('variant', ['cem', 'safe'])
-@pytest.mark.parametrize('rc', [1, 2])
+@pytest.mark.parametrize('rc', [1, 2, 3, 4])
 @pytest.mark.parametrize('dims', [(60, 2), (100, 12)], ids=['obs60', 'obs100'])
 def test_scores_match_oracle_and_fp32_kernel(variant, rc, dims):
     """Per-candidate scores of one iteration on dumped noise: split vs the fp64 oracle at the fp32 kernels' bound (near-threshold
@@ -70,7 +70,7 @@ def test_rank_shards_and_tile_sizes_are_bit_identical_within_the_split_kernel():
     pb = hp.make_problem(60, 2, 5, 4, seed=33)
     N, H, P, E, k, I = 512, 10, 5, 5, 51, 2
     ref = None
-    for rc in (1, 2):
+    for rc in (1, 2, 3, 4, 0):
         _, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, precision='bf16x3', chunks_per_tile=rc)
         pl = hp.make_planner(pb, pcfg)
         a, s, it = pl.plan(pb['state'], seed=9, call=4)
