@@ -24,6 +24,7 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
 PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+PEAK_BF16_MFMA_TFLOPS = 2516.6     # MI355X_MICROARCH.md: dense bf16 MFMA = 16 x the fp32 matrix rate (the split leg's pipe)
 SHADER_CLOCK_HZ = 2.4e9            # MI355X peak engine clock (MI355X_MICROARCH.md)
 
 
@@ -46,6 +47,48 @@ def rollout_kernel_name(pl, obs, act):
     if pl.segments()[0] > 1:
         return 'void cem_rollout_seg_kernel<%d, %d>(RolloutParams)' % (rc, nfw)
     return 'void cem_rollout_kernel<%d, %d, 0>(RolloutParams)' % (rc, nfw)
+
+
+def split_leg(torch, pb, dev, steps, warmup, n_per_gpu):
+    """The SAME workload on the opt-in split-product rollout (PlannerConfig.precision = 'bf16x3', csrc/cem_rollout_split.h): every fp32
+    product formed from exact three-way bf16 splits as six bf16 MFMAs, fp32 accumulate — scores within the fp32 kernels' own distance
+    of the oracle (tests/test_gpu_split.py).  A separately labelled line: never part of `value`, which is the fp32-MFMA path."""
+    from ethz_safe_learning_amd import CemPlanner, PlannerConfig, synthetic
+    obs, act, K, H, I, N = 60, 2, 5, 30, 5, n_per_gpu
+    cfg = PlannerConfig(obs_dim=obs, act_dim=act, ensemble_size=K, particles=K, n_samples=N, horizon=H, n_elite=N // 10, iterations=I,
+                        scorer=pb['scorer'], act_low=pb['low'], act_high=pb['high'], stddev_threshold=-1.0, noise_stddev=1e-3, variant='cem',
+                        precision='bf16x3', use_graph=True)
+    pl = CemPlanner(cfg, device=dev)
+    pl.set_weights(pb['weights'])
+    pl.set_normaliser(pb['inputs_min'], pb['inputs_max'])
+    for i in range(warmup):
+        pl.plan(pb['state'], seed=2026, call=i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        a, s, it = pl.plan(pb['state'], seed=2026, call=warmup + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert it == I and np.all(np.isfinite(a))
+    pl.set_timing(True)
+    roll_ms, roll_n = 0.0, 0
+    for i in range(5):
+        pl.plan(pb['state'], seed=2027, call=i)
+        tm = pl.last_timing()
+        roll_ms += tm['rollout_ms']; roll_n += tm['rollout_launches']
+    pl.set_timing(False)
+    avg_ms = roll_ms / max(roll_n, 1)
+    flops_launch = synthetic.flops_per_row_step(obs, act) * K * N * H
+    rc = pl.tiles()[0]
+    out = dict(label='opt-in: fp32 products as six bf16 MFMAs of exact three-way splits (precision bf16x3); NOT the headline value',
+               value=steps / dt, unit='plans/s', ms_per_step=1e3 * dt / steps, steps=steps, chunks_per_tile=rc, tiles=int(len(pl.tiles()[1])),
+               kernel='void cem_rollout_split_kernel<%d, 1, 0>(RolloutParams)' % rc, rollout_ms_per_launch=avg_ms,
+               algorithmic_tflops=flops_launch / (avg_ms * 1e-3) / 1e12,
+               matrix_pipe_tflops=flops_launch * 6.0 / (avg_ms * 1e-3) / 1e12, matrix_pipe_peak_tflops=PEAK_BF16_MFMA_TFLOPS,
+               matrix_pipe_frac=flops_launch * 6.0 / (avg_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+               candidate_trajectory_steps_per_s=steps / dt * I * N * H, hip_graph=pl.graph_status() == 'graph')
+    pl.close()
+    return out
 
 
 def cpu_baseline(budget_s=25.0):
@@ -208,6 +251,7 @@ def main():
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-split-leg', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--chunks', type=int, default=0)
     ap.add_argument('--segments', type=int, default=0, help='rollout work-queue segments: 0 auto, 1 off')
@@ -369,6 +413,8 @@ def main():
             pl.comm_destroy()                          # one communicator at a time
         out['b5'] = b5_leg(torch, dist, pb, G, rank, dev, native, steps=min(args.steps, 20), warmup=min(max(args.warmup, 2), 5),
                            rehearse_world=rehearse if G == 1 else 0, ctl_dev=ctl_dev)
+    if G == 1 and not distributed and not args.no_split_leg:
+        out['split_bf16x3'] = split_leg(torch, pb, dev, steps=min(args.steps, 50), warmup=min(max(args.warmup, 3), 10), n_per_gpu=args.n_per_gpu)
     if rank == 0 and G == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     if rank == 0:
