@@ -15,7 +15,7 @@ class CemMpc(MpcPolicy):
     variant = 'cem'
 
     def __init__(self, model, environment, horizon, iterations, smoothing, n_samples, n_elite, particles,
-                 stddev_threshold, noise_stddev, seed=0, device='cuda:0', use_graph=True):
+                 stddev_threshold, noise_stddev, seed=0, device='cuda:0', use_graph=True, precision='fp32'):
         super().__init__(model, environment, horizon, n_samples, particles)
         self.iterations = iterations
         self.smoothing = smoothing
@@ -25,6 +25,7 @@ class CemMpc(MpcPolicy):
         self.seed = seed
         self.device = device
         self.use_graph = use_graph
+        self.precision = precision                     # 'fp32' | 'bf16x3' (PlannerConfig.precision; beyond the reference's kwargs)
         self._planner = None
         self.last_score = None
         self.last_iterations = None
@@ -50,7 +51,7 @@ class CemMpc(MpcPolicy):
             act_high=self.action_space.high, units=ens.mlp_params['units'], n_layers=ens.mlp_params['n_layers'], activation=ens.activation,
             smoothing=self.smoothing, stddev_threshold=self.stddev_threshold, noise_stddev=self.noise_stddev,
             variant=self.variant, sampling_propagation=m.sampling_propagation, scale_features=m.scale_features,
-            use_graph=self.use_graph, **self._extra_config())
+            use_graph=self.use_graph, precision=self.precision, **self._extra_config())
 
     def build(self):
         if self._planner is None or self._planner.h is None:      # never built, or closed by its owner

@@ -21,7 +21,7 @@ MODELS_YAML = dict(ensemble_size=15, batch_size=64, validation_split=0.2, learni
                    training_steps=5000, mlp_params=dict(n_layers=4, units=128, activation='tf.nn.relu', dropout_rate=0.0))
 
 
-def make_agent_parts(policy_name, seed=0, units=None, activation=None, dropout_rate=None):
+def make_agent_parts(policy_name, seed=0, units=None, activation=None, dropout_rate=None, precision=None):
     """What MbrlAgent.__init__ does (mbrl_agent.py:27-35,103-118; agent_factory.py:22 injects train_epochs)."""
     env = SyntheticSafetyGym()
     model_params = dict(MODELS_YAML, scale_features=True, train_epochs=10, seed=seed)
@@ -35,6 +35,8 @@ def make_agent_parts(policy_name, seed=0, units=None, activation=None, dropout_r
                             sampling_propagation=True, **model_params)
     policy_params = dict(POLICIES_YAML[policy_name])
     policy_params['environment'] = env
+    if precision is not None:
+        policy_params['precision'] = precision
     policy = eval(standardize_name(policy_name))(model=model, **policy_params)
     return env, model, policy
 
@@ -121,11 +123,13 @@ def test_box():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
 @pytest.mark.parametrize('policy_name', ['cem_mpc', 'safe_cem_mpc'])
-def test_generate_action_at_shipped_config_matches_oracle(policy_name):
+def test_generate_action_at_shipped_config_matches_oracle(policy_name, precision):
     """policy.generate_action contract (agent.py:120,146) + parity at the reference's own hyper-parameters:
-    E=15 with P=5,N=150 (candidates of one particle hit three members) and P=45,N=500 (three particles per member)."""
-    env, model, pol = make_agent_parts(policy_name, seed=3)
+    E=15 with P=5,N=150 (candidates of one particle hit three members) and P=45,N=500 (three particles per member) — on the fp32
+    kernels and on the split-product rollout (the policy kwarg `precision`), same oracle, same tolerances."""
+    env, model, pol = make_agent_parts(policy_name, seed=3, precision=None if precision == 'fp32' else precision)
     trained_like(model, np.random.default_rng(1))
     pp = POLICIES_YAML[policy_name]
     I, N, H, P = pp['iterations'], pp['n_samples'], pp['horizon'], pp['particles']
