@@ -23,7 +23,7 @@ def main():
     torch.cuda.set_device(0)
     pb = hp.make_problem(seed=case['seed'])
     _, cfg = hp.configs(pb, N=case['N'], H=case['H'], P=5, E=5, k=case['k'], I=case['I'], variant=case['variant'], post=0.3, noise=0.02,
-                        use_graph=True, world_size=world, rank=rank, select_mode=case.get('select_mode', 0))
+                        use_graph=True, world_size=world, rank=rank, select_mode=case.get('select_mode', 0), precision=case.get('precision', 'fp32'))
     pl = hp.make_planner(pb, cfg)
     pl.comm_init()
     assert pl.comm_ranks() == world

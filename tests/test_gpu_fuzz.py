@@ -29,10 +29,13 @@ def _random_rollout_case(seed):
     else:
         P = int(rng.integers(1, 5))                        # members split particles: P * N must divide by E
         N = E * int(rng.integers(1, 40))
-    return dict(O=O, A=A, E=E, P=P, N=N, H=int(rng.integers(1, 11)), L=int(rng.integers(1, 6)),
-                units=int(rng.choice([16, 17, 33, 64, 100, 127, 128, 129, 160, 200, 256])), variant=str(rng.choice(['cem', 'safe'])),
-                rc=int(rng.integers(0, 5)), seg=int(rng.choice([0, 0, 1, 2, 3])), sampling=bool(rng.random() < 0.8),
-                scale=bool(rng.random() < 0.8), post=float(rng.choice([0.15, 0.3, 0.5])))
+    c = dict(O=O, A=A, E=E, P=P, N=N, H=int(rng.integers(1, 11)), L=int(rng.integers(1, 6)),
+             units=int(rng.choice([16, 17, 33, 64, 100, 127, 128, 129, 160, 200, 256])), variant=str(rng.choice(['cem', 'safe'])),
+             rc=int(rng.integers(0, 5)), seg=int(rng.choice([0, 0, 1, 2, 3])), sampling=bool(rng.random() < 0.8),
+             scale=bool(rng.random() < 0.8), post=float(rng.choice([0.15, 0.3, 0.5])))
+    # (drawn last, so the cases above are the ones of earlier rounds) the split-product rollout where it applies: half of the eligible cases
+    c['precision'] = 'bf16x3' if (c['units'] <= 128 and rng.random() < 0.5) else 'fp32'
+    return c
 
 
 @pytest.mark.parametrize('seed', range(32 * SCALE))
@@ -41,7 +44,8 @@ def test_random_shape_rollout_scores(seed):
     O, A, E, P, N, H = c['O'], c['A'], c['E'], c['P'], c['N'], c['H']
     pb = hp.make_problem(O, A, E, c['L'], seed=200 + seed, units=c['units'])
     ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=max(1, N // 10), I=1, variant=c['variant'], post=c['post'],
-                            sampling=c['sampling'], scale=c['scale'], chunks_per_tile=c['rc'], rollout_segments=c['seg'])
+                            sampling=c['sampling'], scale=c['scale'], chunks_per_tile=c['rc'], rollout_segments=c['seg'],
+                            precision=c['precision'])
     pl = hp.make_planner(pb, pcfg)
     ea, em, eo = hp.noise(1, N, H, A, P, O, seed=seed)
     actions, returns, scores = _run_iteration(pl, pb, ocfg, ea, em)

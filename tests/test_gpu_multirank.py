@@ -48,6 +48,8 @@ CASES = [
     dict(name='w3_fused_select', world=3, N=24576, H=6, k=2457, I=2, variant='cem', seed=84, plan_seed=5, calls=3),
     # the 8-launch select chain under the graph, two ranks
     dict(name='w2_chain_select', world=2, N=4096, H=8, k=409, I=3, variant='cem', seed=85, plan_seed=9, calls=3, select_mode=2),
+    # the split-product rollout, sharded
+    dict(name='w2_split_precision', world=2, N=1024, H=8, k=102, I=3, variant='safe', seed=86, plan_seed=3, calls=3, precision='bf16x3'),
 ]
 
 
@@ -57,7 +59,7 @@ def test_every_rank_of_a_sharded_plan_equals_the_single_rank_plan(case, fake_rcc
     # reference first (this process holds the GPU too: world + 1 processes on the card, within the box's limit of 6)
     pb = hp.make_problem(seed=case['seed'])
     _, cfg = hp.configs(pb, N=case['N'], H=case['H'], P=5, E=5, k=case['k'], I=case['I'], variant=case['variant'], post=0.3, noise=0.02,
-                        use_graph=True, select_mode=case.get('select_mode', 0))
+                        use_graph=True, select_mode=case.get('select_mode', 0), precision=case.get('precision', 'fp32'))
     ref = hp.make_planner(pb, cfg)
     expect = []
     for c in range(case['calls']):
