@@ -114,40 +114,49 @@ __device__ __forceinline__ void cem_split_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], 
                                                 const int lane, const int w)
 {
     static_assert(NCH % CEM_SPLIT_RING == 0, "stage lengths must keep the ring phase");
+    constexpr int FL = OWN ? 1 : 0;                        // visiting position of the first chunk that comes from LDS
     cem_u4 bp[2][RC][3];                                   // B planes of the chunk in use and of the next one
+    // the six products of one chunk for both output blocks, smallest terms first: (weight plane, activation plane)
+    // (2,0) (1,1) (0,2) | (1,0) (0,1) (0,0); HALF 0 / 1 = the first / last three (the own chunk straddles the barrier)
+#define CEM_SPLIT_PRODUCTS(G_, B0_, B1_, B2_, C_, HALF_) do { \
+        if ((HALF_) != 1) { \
+            acc0[C_] = CEM_MFMA_BF((G_)[2], B0_, acc0[C_]); acc1[C_] = CEM_MFMA_BF((G_)[5], B0_, acc1[C_]); \
+            acc0[C_] = CEM_MFMA_BF((G_)[1], B1_, acc0[C_]); acc1[C_] = CEM_MFMA_BF((G_)[4], B1_, acc1[C_]); \
+            acc0[C_] = CEM_MFMA_BF((G_)[0], B2_, acc0[C_]); acc1[C_] = CEM_MFMA_BF((G_)[3], B2_, acc1[C_]); } \
+        if ((HALF_) != 0) { \
+            acc0[C_] = CEM_MFMA_BF((G_)[1], B0_, acc0[C_]); acc1[C_] = CEM_MFMA_BF((G_)[4], B0_, acc1[C_]); \
+            acc0[C_] = CEM_MFMA_BF((G_)[0], B1_, acc0[C_]); acc1[C_] = CEM_MFMA_BF((G_)[3], B1_, acc1[C_]); \
+            acc0[C_] = CEM_MFMA_BF((G_)[0], B0_, acc0[C_]); acc1[C_] = CEM_MFMA_BF((G_)[3], B0_, acc1[C_]); } } while (0)
+#define CEM_SPLIT_READ(Q_) do { const int F_ = OWN ? cem_split_perm(w, (Q_)) : (Q_); \
+        _Pragma("unroll") for (int c = 0; c < RC; ++c) \
+            _Pragma("unroll") for (int j = 0; j < 3; ++j) \
+                bp[(Q_) & 1][c][j] = *reinterpret_cast<const cem_u4 *>(smem + xr + cem_split_off(c, F_, j, lane)); } while (0)
 #pragma unroll
     for (int P = 0; P < NCH; ++P) {
         wq.ld(wq.slot[(P + CEM_SPLIT_RING - 1) % CEM_SPLIT_RING], wq.pos);     // the group RING - 1 chunks ahead (possibly the next stage's)
         wq.pos = (wq.pos + 1 == wq.n) ? 0 : wq.pos + 1;
         __builtin_amdgcn_sched_barrier(0);
-        if (XMODE == CEM_X_EXCHANGE && P == (OWN ? 1 : 0)) __syncthreads();
-        // activation planes from LDS: the first chunk that is not in registers right after the barrier, every later one a chunk ahead
-        constexpr int FL = OWN ? 1 : 0;
-#pragma unroll
-        for (int Q = P; Q <= P + 1 && Q < NCH; ++Q) {
-            if ((Q == P && P == FL) || (Q == P + 1 && Q > FL)) {
-                const int F = OWN ? cem_split_perm(w, Q) : Q;
-#pragma unroll
-                for (int c = 0; c < RC; ++c)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) bp[Q & 1][c][j] = *reinterpret_cast<const cem_u4 *>(smem + xr + cem_split_off(c, F, j, lane));
-            }
-        }
         const cem_u4 (&g)[6] = wq.slot[P % CEM_SPLIT_RING];
+        if (OWN && P == 0) {
+            // the wave's own chunk: half of its MFMAs cover the wait at the barrier, the other half the LDS round trip of chunk 1
 #pragma unroll
-        for (int c = 0; c < RC; ++c) {
-            const cem_u4 b0 = (OWN && P == 0) ? own[c][0] : bp[P & 1][c][0];
-            const cem_u4 b1 = (OWN && P == 0) ? own[c][1] : bp[P & 1][c][1];
-            const cem_u4 b2 = (OWN && P == 0) ? own[c][2] : bp[P & 1][c][2];
-            // smallest terms first: (2,0) (1,1) (0,2) | (1,0) (0,1) | (0,0)   (weight plane, activation plane)
-            acc0[c] = CEM_MFMA_BF(g[2], b0, acc0[c]); acc1[c] = CEM_MFMA_BF(g[5], b0, acc1[c]);
-            acc0[c] = CEM_MFMA_BF(g[1], b1, acc0[c]); acc1[c] = CEM_MFMA_BF(g[4], b1, acc1[c]);
-            acc0[c] = CEM_MFMA_BF(g[0], b2, acc0[c]); acc1[c] = CEM_MFMA_BF(g[3], b2, acc1[c]);
-            acc0[c] = CEM_MFMA_BF(g[1], b0, acc0[c]); acc1[c] = CEM_MFMA_BF(g[4], b0, acc1[c]);
-            acc0[c] = CEM_MFMA_BF(g[0], b1, acc0[c]); acc1[c] = CEM_MFMA_BF(g[3], b1, acc1[c]);
-            acc0[c] = CEM_MFMA_BF(g[0], b0, acc0[c]); acc1[c] = CEM_MFMA_BF(g[3], b0, acc1[c]);
+            for (int c = 0; c < RC; ++c) CEM_SPLIT_PRODUCTS(g, own[c][0], own[c][1], own[c][2], c, 0);
+            if (XMODE == CEM_X_EXCHANGE) __syncthreads();
+            if (NCH > 1) CEM_SPLIT_READ(1);
+#pragma unroll
+            for (int c = 0; c < RC; ++c) CEM_SPLIT_PRODUCTS(g, own[c][0], own[c][1], own[c][2], c, 1);
+            continue;
         }
+        if (!OWN && P == 0) {
+            if (XMODE == CEM_X_EXCHANGE) __syncthreads();
+            CEM_SPLIT_READ(0);
+        }
+        if (P + 1 < NCH && P + 1 > FL) CEM_SPLIT_READ(P + 1);       // a chunk ahead of its MFMAs
+#pragma unroll
+        for (int c = 0; c < RC; ++c) CEM_SPLIT_PRODUCTS(g, bp[P & 1][c][0], bp[P & 1][c][1], bp[P & 1][c][2], c, 2);
     }
+#undef CEM_SPLIT_PRODUCTS
+#undef CEM_SPLIT_READ
 }
 
 // One tile for the whole horizon (cem_rollout_tile with the split stages; MODE as there)
