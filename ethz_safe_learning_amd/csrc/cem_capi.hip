@@ -1311,10 +1311,9 @@ int cem_unfold_sequences(cem_planner_t *h, const float *s0_dev, const float *act
     if (h->in_plan) return CEM_ERR_STATE;
     const Dims &d = h->d;
     if (n_rows % d.E != 0) return CEM_ERR_SPLIT;
-    if (d.split) return CEM_ERR_UNSUPPORTED;            // the weight stream of a split-precision handle is not the fp32 kernels' (cem_mpc.h)
     if ((long long)n_rows * (horizon + 1) * d.O > 0x7fffffff00ll) return CEM_ERR_UNSUPPORTED;
     const int chunk = n_rows / d.E;
-    const int rc = d.wide ? 1 : (n_rows >= 256 * 64 ? 4 : (n_rows >= 256 * 32 ? 2 : 1));
+    const int rc = d.wide ? 1 : (d.split ? (n_rows >= 256 * 32 ? 2 : 1) : (n_rows >= 256 * 64 ? 4 : (n_rows >= 256 * 32 ? 2 : 1)));
     std::vector<Tile6> tiles;
     for (int m = 0; m < d.E; ++m)
         for (int r = m * chunk; r < (m + 1) * chunk; r += 16 * rc) {
@@ -1332,7 +1331,9 @@ int cem_unfold_sequences(cem_planner_t *h, const float *s0_dev, const float *act
     rp.tiles = dt; rp.s0 = s0_dev; rp.actions = actions_dev; rp.eps_model = eps_model_dev; rp.ret = ret; rp.costs = nullptr;
     rp.traj = traj_out_dev; rp.mu_out = mu_out_dev; rp.sd_out = sd_out_dev;
     rp.H = horizon; rp.Bloc = n_rows; rp.Btot = n_rows; rp.it = 0; rp.variant = 0; rp.check_done = 0;
-    hipError_t e = d.wide ? launch_rollout_wide(h, rp, (int)tiles.size(), 1) : launch_rollout<1>(rc, d.NFW, rp, (int)tiles.size(), h->stream);
+    hipError_t e = d.wide ? launch_rollout_wide(h, rp, (int)tiles.size(), 1)
+                 : d.split ? launch_rollout_split(rc, d.NFW, 1, rp, (int)tiles.size(), h->stream)
+                           : launch_rollout<1>(rc, d.NFW, rp, (int)tiles.size(), h->stream);
     hipError_t e2 = hipStreamSynchronize(h->stream);
     HIPCHK(e); HIPCHK(e2);
     return CEM_OK;

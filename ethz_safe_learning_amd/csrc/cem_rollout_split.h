@@ -12,8 +12,8 @@
 // Structure: cem_rollout_tile's — 4 waves per tile of 16 RC rows of one member for the whole horizon, wave w computes output blocks
 // 2w, 2w + 1 of a hidden layer and keeps them, SPLIT, as its own K = 32 input chunk of the next stage; the other chunks travel through
 // LDS as three bf16 planes; weights stream from a per-wave image of 6 KB groups (chunk x {a, b} output block x 3 planes) in visiting
-// order.  The epilogue, scorer terms and bookkeeping are cem_rollout_tile's own macros.  First version: whole-horizon tiles only
-// (no floating segments), RC <= 2.
+// order.  The epilogue, scorer terms and bookkeeping are cem_rollout_tile's own macros.  Whole-horizon tiles only (no floating
+// segments); MODE 1 also serves cem_unfold_sequences (trajectory / head-moment outputs).
 #pragma once
 #include "cem_device.h"
 
@@ -250,6 +250,14 @@ __device__ __forceinline__ void cem_rollout_tile_split(const RolloutParams &p, c
             for (int c = 0; c < RC; ++c) {
                 f4 act4; CEM_LOAD_ACT(act4, i, c, 0);
                 const f4 sn = s[i][c];
+                if (MODE == 1) {
+                    const int slot = 16 * c + j, f0 = 16 * (w + 4 * i) + 4 * q;
+                    if (p.traj && slot < td.cnt) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (f0 + r < O) p.traj[((size_t)(td.row_base + slot) * (H + 1)) * O + f0 + r] = sn[r];
+                    }
+                }
                 cem_scorer_terms(sn, p.sc.D, sel0, sel1, pm[0][c], pm[1][c]);
                 const f4 x = cem_sub4(__builtin_elementwise_fma(isact4, act4, sn), mn4) * rd4;
                 CEM_PUBLISH_X(x, w + 4 * i, c);
@@ -368,6 +376,19 @@ __device__ __forceinline__ void cem_rollout_tile_split(const RolloutParams &p, c
                 for (int r = 0; r < 4; ++r) sd[r] = __builtin_amdgcn_sqrtf(var[r]);
                 const f4 d = mu + sd * eps4[c];
                 const f4 sn = s[i][c] + d * om4;
+                if (MODE == 1) {
+                    const int slot = 16 * c + j, f0 = 16 * Fo + 4 * q;
+                    if (slot < td.cnt) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (f0 + r < O) {
+                                const size_t o = ((size_t)(td.row_base + slot) * H + t) * O + f0 + r;
+                                if (p.mu_out) p.mu_out[o] = mu[r];
+                                if (p.sd_out) p.sd_out[o] = sd[r];
+                                if (p.traj) p.traj[((size_t)(td.row_base + slot) * (H + 1) + (t + 1)) * O + f0 + r] = sn[r];
+                            }
+                    }
+                }
                 s[i][c] = sn;
                 cem_scorer_terms(sn, p.sc.D, sel0, sel1, pm[0][c], pm[1][c]);
                 const f4 x = cem_sub4(__builtin_elementwise_fma(isact4, act4[c], sn), mn4) * rd4;

@@ -79,7 +79,7 @@ typedef struct cem_scorer {
  * CEM_PRECISION_FP32: v_mfma_f32_16x16x4_f32 (the default; what every number in BASELINE / DESIGN is quoted on unless labelled).
  * CEM_PRECISION_SPLIT_BF16X3: weights and activations as exact three-way bf16 splits, the six leading bf16 x bf16 products per
  * fp32 product on v_mfma_f32_16x16x32_bf16 (csrc/cem_rollout_split.h).  Same oracle, same tolerances, not bit-identical to the
- * fp32 form; units <= 128 and relu only; plans only (cem_unfold_sequences returns CEM_ERR_UNSUPPORTED on such a handle). */
+ * fp32 form; units <= 128 and relu only. */
 enum cem_precision { CEM_PRECISION_FP32 = 0, CEM_PRECISION_SPLIT_BF16X3 = 1 };
 
 /* Constructor kwargs of CemMpc / SafeCemMpc (cem_mpc.py:7-17, safe_cem_mpc.py:8-19)

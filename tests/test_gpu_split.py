@@ -98,11 +98,27 @@ def test_rank_shards_and_tile_sizes_are_bit_identical_within_the_split_kernel():
     pl.close()
 
 
-def test_unfold_is_refused_on_a_split_handle():
+def test_unfold_sequences_on_a_split_handle_matches_the_fp32_kernels_and_the_oracle():
+    """TransitionModel.unfold_sequences (transition_model.py:64-77) through the split kernel's explicit-tensor instantiation."""
     import torch
     pb = hp.make_problem(60, 2, 5, 4, seed=1)
-    _, pcfg = hp.configs(pb, N=64, H=4, P=5, E=5, k=6, I=1, precision='bf16x3')
-    pl = hp.make_planner(pb, pcfg)
-    with pytest.raises(Exception):
-        pl.unfold_sequences(torch.zeros(10, 60), torch.zeros(10, 4, 2))
-    pl.close()
+    rng = np.random.default_rng(4)
+    B, H = 40, 6
+    s0 = rng.normal(0, 0.3, (B, 60)).astype(np.float32)
+    acts = rng.uniform(-1, 1, (B, H, 2)).astype(np.float32)
+    eps = rng.standard_normal((H, B, 60)).astype(np.float32)
+    out = {}
+    for prec in ('fp32', 'bf16x3'):
+        _, pcfg = hp.configs(pb, N=64, H=4, P=5, E=5, k=6, I=1, precision=prec)
+        pl = hp.make_planner(pb, pcfg)
+        traj, mu, sd = pl.unfold_sequences(s0, acts, eps_model=eps, return_moments=True)
+        torch.cuda.synchronize()
+        out[prec] = (traj.cpu().numpy(), mu.cpu().numpy(), sd.cpu().numpy())
+        pl.close()
+    members = np.arange(B) // (B // 5)                       # mlp_ensemble.py:123-126: contiguous chunks of B / E rows
+    ref = o.unfold_sequences(s0.astype(np.float64), acts.astype(np.float64), o.cast_weights(pb['weights'], np.float64), members,
+                             pb['inputs_min'], pb['inputs_max'], eps)
+    for prec in out:
+        np.testing.assert_allclose(out[prec][0], ref, rtol=2e-5, atol=2e-5, err_msg=prec)
+    for a, b in zip(out['fp32'], out['bf16x3']):
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-5)
