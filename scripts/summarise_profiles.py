@@ -5,7 +5,7 @@ from collections import defaultdict
 
 out = sys.argv[1]
 workload = sys.argv[2] if len(sys.argv) > 2 else 'B2'
-cmd = sys.argv[3] if len(sys.argv) > 3 else 'bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-graph'
+cmd = sys.argv[3] if len(sys.argv) > 3 else 'bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-split-leg --no-graph'
 # 1. kernel stats: copy the rocprofv3 summary as is
 for f in glob.glob(os.path.join(out, 'stats', '**', '*kernel_stats.csv'), recursive=True):
     open(os.path.join(out, 'summary_kernel_stats.csv'), 'w').write(open(f).read())
@@ -29,8 +29,10 @@ with open(os.path.join(out, 'summary_pmc.csv'), 'w') as fh:
     fh.write('kernel,counter,dispatches,mean_per_dispatch,pass\n')
     for r in rows:
         fh.write('"%s",%s,%d,%g,%s\n' % r)
-roll = {c: m for k, c, n, m, p in rows if 'cem_rollout_' in k}
-kern = next((k for k, c, n, m, p in rows if 'cem_rollout_' in k), None)
+# ONE kernel's counters: the rollout instantiation of the profiled workload (the fp32 headline path; a run that also launched the
+# opt-in split kernel or another instantiation must not mix their rows in)
+kern = next((k for k, c, n, m, p in rows if 'cem_rollout_' in k and 'split' not in k), None)
+roll = {c: m for k, c, n, m, p in rows if k == kern}
 if roll:
     hit, miss = roll.get('TCC_HIT_sum', 0.0), roll.get('TCC_MISS_sum', 0.0)
     t = {'kernel': kern, 'workload': workload, 'fetch_size_kb': roll.get('FETCH_SIZE'), 'write_size_kb': roll.get('WRITE_SIZE'),
