@@ -45,6 +45,8 @@ _, cfg = hp.configs(pb, N=2000, H=30, P=5, E=5, k=200, I=5, variant='safe', post
 leg('B2 safe', pb, cfg)
 _, cfg = hp.configs(pb, N=2000, H=30, P=5, E=5, k=200, I=5, use_graph=True)
 leg('B2 cem, weights re-staged / 500', pb, cfg, restage_every=500)
+_, cfg = hp.configs(pb, N=2000, H=30, P=5, E=5, k=200, I=5, use_graph=True, precision='bf16x3')
+leg('B2 cem, split-product rollout', pb, cfg, restage_every=700)
 pbw = hp.make_problem(60, 2, 5, 4, seed=1, units=192, activation='tanh')
 _, cfg = hp.configs(pbw, N=1000, H=20, P=5, E=5, k=100, I=4, use_graph=True)
 leg('generic kernel: 192 units, tanh', pbw, cfg)
