@@ -1,10 +1,10 @@
 // cem_rollout_split.h — the rollout with every fp32 product formed on the bf16 matrix pipe from EXACT three-way splits
 // (config field `precision` = CEM_PRECISION_SPLIT_BF16X3; opt-in, never the default).
 //
-// An fp32 number is the exact sum of three bf16 numbers, x = x0 + x1 + x2 (8 significand bits each, truncation split: x0 = the top
-// half of x's bit pattern, x1 = the top half of x - x0, x2 = x - x0 - x1).  A product w * x is then the sum of nine bf16 x bf16
-// products, each exact in the fp32 accumulator of v_mfma_f32_16x16x32_bf16; the six with i + j <= 2 carry everything down to
-// 2^-24 of the product — what an fp32 FMA keeps — and the other three are dropped.  Six bf16 MFMAs of K = 32 replace eight fp32
+// An fp32 number is the exact sum of three bf16 numbers, x = x0 + x1 + x2 (8 significand bits each: x0 = RN(x), x1 = RN(x - x0),
+// x2 = x - x0 - x1, round to nearest even).  A product w * x is then the sum of nine bf16 x bf16 products, each exact in the fp32
+// accumulator of v_mfma_f32_16x16x32_bf16; the six with i + j <= 2 carry everything down to 2^-23 of the product — the scale of
+// one fp32 rounding — and the other three are dropped.  Six bf16 MFMAs of K = 32 replace eight fp32
 // MFMAs of K = 4 per (two input blocks x one output block): 96 matrix-pipe cycles instead of 256, and VALU work issues beside bf16
 // MFMAs instead of taking their slots.  Not bit-identical to the fp32 kernels (the products are summed inside the MFMA, 32 at a
 // time), same error scale; parity is measured against the same oracle at the same tolerances (tests/test_gpu_split.py).
@@ -22,51 +22,51 @@ typedef unsigned int cem_u2 __attribute__((ext_vector_type(2)));
 #define CEM_MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cem_bf8, (a)), __builtin_bit_cast(cem_bf8, (b)), (c), 0, 0, 0)
 #define CEM_SPLIT_CHUNKS 4                   // K = 32 chunks of a 128-feature layer
 
-// x -> (x0, x1, x2) as bit patterns whose upper halves are the bf16 pieces (host and device: the same operations)
+// x -> (x0, x1, x2) as bit patterns whose upper halves are the bf16 pieces: x0 = RN(x), x1 = RN(x - x0), x2 = x - x0 - x1 with RN =
+// round to nearest even at 8 significand bits (what v_cvt_pk_bf16_f32 does).  Both subtractions are exact and x2 has at most 8
+// significant bits, so x = x0 + x1 + x2 exactly (|x| below the largest bf16, 3.39e38) with |x1| <= 2^-8 |x|, |x2| <= 2^-16 |x|:
+// the three dropped products are below 2^-23 of w x.  (A truncation split is exact too, but its pieces only shrink by 2^-7 each:
+// the dropped terms reach 2^-21; tests/test_split_cpu.py.)  Host version (weights); the device splits pairs, below.
+__host__ __device__ inline unsigned cem_rn_bf16_bits(const float x)
+{
+    union { float f; unsigned u; } v; v.f = x;
+    return (v.u + 0x7FFFu + ((v.u >> 16) & 1u)) & 0xFFFF0000u;
+}
 __host__ __device__ inline void cem_split3_bits(const float x, unsigned &a0, unsigned &a1, unsigned &a2)
 {
-    union { float f; unsigned u; } v, r1, r2, t;
-    v.f = x; a0 = v.u & 0xFFFF0000u;
-    t.u = a0; r1.f = x - t.f; a1 = r1.u & 0xFFFF0000u;
-    t.u = a1; r2.f = r1.f - t.f; a2 = r2.u;
+    union { float f; unsigned u; } t, r1, r2;
+    a0 = cem_rn_bf16_bits(x);
+    t.u = a0; r1.f = x - t.f; a1 = cem_rn_bf16_bits(r1.f);
+    t.u = a1; r2.f = r1.f - t.f; a2 = r2.u;                 // exactly a bf16 value already
 }
 
+typedef __bf16 cem_bf2 __attribute__((ext_vector_type(2)));
+// two values -> their three pieces, one packed word per plane: 11 VALU instructions (3 v_cvt_pk_bf16_f32, 4 shifts / masks, 4 subtractions)
+__device__ __forceinline__ void cem_split_pair(const float x0, const float x1, unsigned &p0, unsigned &p1, unsigned &p2)
+{
+    p0 = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){x0, x1}, cem_bf2));
+    const float r1l = x0 - __uint_as_float(p0 << 16), r1h = x1 - __uint_as_float(p0 & 0xFFFF0000u);
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){r1l, r1h}, cem_bf2));
+    const float r2l = r1l - __uint_as_float(p1 << 16), r2h = r1h - __uint_as_float(p1 & 0xFFFF0000u);
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){r2l, r2h}, cem_bf2));
+}
 // 8 values (two accumulator quads: features 4q..4q+3 of two 16-feature blocks) -> three planes of 8 bf16
 __device__ __forceinline__ void cem_split8(const f4 x0, const f4 x1, cem_u4 (&p)[3])
 {
-    const float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-    unsigned a0[8], a1[8], a2[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        a0[i] = __float_as_uint(v[i]) & 0xFFFF0000u;
-        const float r1 = v[i] - __uint_as_float(a0[i]);
-        a1[i] = __float_as_uint(r1) & 0xFFFF0000u;
-        a2[i] = __float_as_uint(r1 - __uint_as_float(a1[i]));
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        p[0][i] = __builtin_amdgcn_perm(a0[2 * i + 1], a0[2 * i], 0x07060302u);     // the upper halves of two words -> one word
-        p[1][i] = __builtin_amdgcn_perm(a1[2 * i + 1], a1[2 * i], 0x07060302u);
-        p[2][i] = __builtin_amdgcn_perm(a2[2 * i + 1], a2[2 * i], 0x07060302u);
-    }
+    unsigned a[4], b[4], c[4];
+    cem_split_pair(x0[0], x0[1], a[0], b[0], c[0]);
+    cem_split_pair(x0[2], x0[3], a[1], b[1], c[1]);
+    cem_split_pair(x1[0], x1[1], a[2], b[2], c[2]);
+    cem_split_pair(x1[2], x1[3], a[3], b[3], c[3]);
+    p[0] = (cem_u4){a[0], a[1], a[2], a[3]}; p[1] = (cem_u4){b[0], b[1], b[2], b[3]}; p[2] = (cem_u4){c[0], c[1], c[2], c[3]};
 }
 // 4 values (one feature quad of one block) -> three planes of 4 bf16
 __device__ __forceinline__ void cem_split4(const f4 x, cem_u2 (&p)[3])
 {
-    unsigned a0[4], a1[4], a2[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        a0[i] = __float_as_uint(x[i]) & 0xFFFF0000u;
-        const float r1 = x[i] - __uint_as_float(a0[i]);
-        a1[i] = __float_as_uint(r1) & 0xFFFF0000u;
-        a2[i] = __float_as_uint(r1 - __uint_as_float(a1[i]));
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        p[0][i] = __builtin_amdgcn_perm(a0[2 * i + 1], a0[2 * i], 0x07060302u);
-        p[1][i] = __builtin_amdgcn_perm(a1[2 * i + 1], a1[2 * i], 0x07060302u);
-        p[2][i] = __builtin_amdgcn_perm(a2[2 * i + 1], a2[2 * i], 0x07060302u);
-    }
+    unsigned a[2], b[2], c[2];
+    cem_split_pair(x[0], x[1], a[0], b[0], c[0]);
+    cem_split_pair(x[2], x[3], a[1], b[1], c[1]);
+    p[0] = (cem_u2){a[0], a[1]}; p[1] = (cem_u2){b[0], b[1]}; p[2] = (cem_u2){c[0], c[1]};
 }
 
 // chunk visited at position phi of a hidden / heads stage by wave w: its own chunk (blocks 2w, 2w + 1) first, the others ascending
