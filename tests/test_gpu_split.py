@@ -122,3 +122,49 @@ def test_unfold_sequences_on_a_split_handle_matches_the_fp32_kernels_and_the_ora
         np.testing.assert_allclose(out[prec][0], ref, rtol=2e-5, atol=2e-5, err_msg=prec)
     for a, b in zip(out['fp32'], out['bf16x3']):
         np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-5)
+
+
+def test_b2_full_size_on_the_split_kernel():
+    """BASELINE config B2 at full size on the split kernel's own Philox draws: determinism, two half-shards = the single rank bit for
+    bit, and 64 RANDOM candidates (first, last, the last member's tiles, the rest uniform) against the fp64 oracle on the dumped
+    noise — both objectives."""
+    from tests.test_gpu_parity import _oracle_on_candidates, _random_candidates, FULL_SIZE_ATOL
+    pb = hp.make_problem(seed=1234, bias_noise=0.0)
+    N, H, P, E, k, I = 2000, 30, 5, 5, 200, 2
+
+    def scores_of(planner):
+        planner.plan_begin(pb['state'], seed=3, call=1)
+        planner.plan_rollout(0)
+        planner.plan_end()
+        return planner.scores_local().cpu().numpy().copy()
+    for variant in ('cem', 'safe'):
+        ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, variant=variant, post=0.3, precision='bf16x3')
+        pl = hp.make_planner(pb, pcfg)
+        s_a = scores_of(pl)
+        np.testing.assert_array_equal(s_a, scores_of(pl))
+        if variant == 'cem':
+            halves = []
+            for r in range(2):
+                _, c2 = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, precision='bf16x3', world_size=2, rank=r)
+                halves.append(scores_of(hp.make_planner(pb, c2)))
+            np.testing.assert_array_equal(np.concatenate(halves), s_a)
+        cand, _, _ = _random_candidates(pl, N, 64, seed=17)
+        a0, ref, traj = _oracle_on_candidates(pl, pb, ocfg, cand, 3, 1, P, N, H, 2, E)
+        err, n_near, n_flip = hp.assert_scores_match_oracle(s_a[cand], traj, P, len(cand), pb['scorer'], variant, 0.3, FULL_SIZE_ATOL, 'B2 split ' + variant)
+        print('B2 split %s: max|gpu-f64| = %.3g over %d random candidates (%d near a threshold, %d flipped)' % (variant, err, len(cand), n_near, n_flip))
+        pl.close()
+
+
+def test_b1_reference_scale_plan_on_the_split_kernel():
+    """BASELINE config B1 (N = 500, H = 25, 5 iterations), the whole plan against the oracle on identical noise tensors."""
+    pb = hp.make_problem(60, 2, 5, 4, seed=1234, bias_noise=0.0)
+    N, H, P, E, k, I = 500, 25, 5, 5, 50, 5
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, noise=1e-3, precision='bf16x3')
+    pl = hp.make_planner(pb, pcfg)
+    ea, em, eo = hp.noise(I, N, H, 2, P, 60, seed=77)
+    ra, rs, rit = o.do_generate_action(pb['state'], pb['weights'], pb['inputs_min'], pb['inputs_max'], pb['low'], pb['high'],
+                                       ea, em, eo, ocfg, pb['scorer'])
+    a, s, it = pl.plan(pb['state'], eps_act=ea, eps_model=em, eps_out=eo)
+    assert it == rit and abs(s - rs) <= 2e-5, (s, rs)
+    np.testing.assert_allclose(a, ra, rtol=1e-5, atol=1e-6)
+    pl.close()
