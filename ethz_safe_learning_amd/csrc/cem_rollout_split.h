@@ -5,9 +5,11 @@
 // x2 = x - x0 - x1, round to nearest even).  A product w * x is then the sum of nine bf16 x bf16 products, each exact in the fp32
 // accumulator of v_mfma_f32_16x16x32_bf16; the six with i + j <= 2 carry everything down to 2^-23 of the product — the scale of
 // one fp32 rounding — and the other three are dropped.  Six bf16 MFMAs of K = 32 replace eight fp32
-// MFMAs of K = 4 per (two input blocks x one output block): 96 matrix-pipe cycles instead of 256, and VALU work issues beside bf16
-// MFMAs instead of taking their slots.  Not bit-identical to the fp32 kernels (the products are summed inside the MFMA, 32 at a
-// time), same error scale; parity is measured against the same oracle at the same tolerances (tests/test_gpu_split.py).
+// MFMAs of K = 4 per (two input blocks x one output block): 96 matrix-pipe cycles instead of 256.  (A wave's VALU work still adds
+// to its MFMA time — interleaving the publish with the next row-chunk's MFMAs gained nothing, profiles/r03_split_tile_sizes.txt —
+// so the split itself, 44 VALU per 8 values, is part of the price.)  Not bit-identical to the fp32 kernels (the products are summed
+// inside the MFMA, 32 at a time), same error scale; parity is measured against the same oracle at the same tolerances
+// (tests/test_gpu_split.py).
 //
 // Structure: cem_rollout_tile's — 4 waves per tile of 16 RC rows of one member for the whole horizon, wave w computes output blocks
 // 2w, 2w + 1 of a hidden layer and keeps them, SPLIT, as its own K = 32 input chunk of the next stage; the other chunks travel through
