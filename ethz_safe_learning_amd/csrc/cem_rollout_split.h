@@ -341,6 +341,19 @@ __device__ __forceinline__ void cem_rollout_tile_split(const RolloutParams &p, c
             const f4 bm = i == 0 ? bm0 : cem_ld_tab(et_rs, tv, CEM_ET_BMU * 512), bv = i == 0 ? bv0 : cem_ld_tab(et_rs, tv, CEM_ET_BVAR * 512);
             const f4 om4 = cem_ld_tab(et_rs, tv, CEM_ET_OBS * 512), isact4 = cem_ld_tab(et_rs, tv, CEM_ET_ACT * 512);
             const f4 sel0 = cem_ld_tab(et_rs, tv, CEM_ET_SEL0 * 512), sel1 = cem_ld_tab(et_rs, tv, CEM_ET_SEL1 * 512);
+            f4 accm[RC], accv[RC];
+#pragma unroll
+            for (int c = 0; c < RC; ++c) { accm[c] = bm; accv[c] = bv; }
+            CEM_STAMP(2);
+            if (Fo < p.KB_obs) {                                                           // wave-uniform
+                if (i == 0) cem_split_stage<RC, CEM_SPLIT_CHUNKS, true, CEM_X_EXCHANGE>(accm, accv, own, wq, smem, xw ^ XB, lane, w);
+                else cem_split_stage<RC, CEM_SPLIT_CHUNKS, true, CEM_X_REREAD>(accm, accv, own, wq, smem, xw ^ XB, lane, w);
+            } else if (i == 0) {
+                __syncthreads();                      // keep the barrier count of waves without observation features
+            }
+            CEM_STAMP(3);
+            // the step's model noise and actions: independent of the heads' MFMAs, so drawn AFTER they are issued — VALU work behind
+            // queued bf16 MFMAs runs in their shadow (scripts/mfma_microbench5.hip -DMB_BF16: 288 MFMAs + 330 VALU take 1.08 x the MFMAs alone)
             f4 act4[RC], eps4[RC];
 #pragma unroll
             for (int c = 0; c < RC; ++c) {
@@ -358,17 +371,6 @@ __device__ __forceinline__ void cem_rollout_tile_split(const RolloutParams &p, c
                                           (uint32_t)(4 * Fo + q), CEM_STREAM_MODEL, key, rscale);
                 }
             }
-            f4 accm[RC], accv[RC];
-#pragma unroll
-            for (int c = 0; c < RC; ++c) { accm[c] = bm; accv[c] = bv; }
-            CEM_STAMP(2);
-            if (Fo < p.KB_obs) {                                                           // wave-uniform
-                if (i == 0) cem_split_stage<RC, CEM_SPLIT_CHUNKS, true, CEM_X_EXCHANGE>(accm, accv, own, wq, smem, xw ^ XB, lane, w);
-                else cem_split_stage<RC, CEM_SPLIT_CHUNKS, true, CEM_X_REREAD>(accm, accv, own, wq, smem, xw ^ XB, lane, w);
-            } else if (i == 0) {
-                __syncthreads();                      // keep the barrier count of waves without observation features
-            }
-            CEM_STAMP(3);
 #pragma unroll
             for (int c = 0; c < RC; ++c) {
                 const f4 mu = accm[c];

@@ -9,6 +9,16 @@
 #include <cstdio>
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
+// -DMB_BF16: the same measurements beside v_mfma_f32_16x16x32_bf16 (the split-product rollout's MFMA; 16 cycles bare)
+#ifdef MB_BF16
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+#define MB_AB_DECL const bf8 av = __builtin_bit_cast(bf8, (u4){(unsigned)threadIdx.x | 0x3c003c00u, 0x3c013c02u, 0x3c033c04u, 0x3c053c06u}), bv = __builtin_bit_cast(bf8, (u4){0x3c073c08u, (unsigned)threadIdx.x | 0x3c003c00u, 0x3c093c0au, 0x3c0b3c0cu});
+#define MB_MFMA(ACC) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, ACC, 0, 0, 0)
+#else
+#define MB_AB_DECL
+#define MB_MFMA(ACC) ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, ACC, 0, 0, 0)
+#endif
 
 enum Op { NONE, FMA, MUL, XOR, MOV, PKMUL, PKFMA, MAD64, EXP, SQRT, SIN, MAX, CNDMASK, PERMSWAP, DSREAD, SNOP, CVT, MULLO };
 static const char *op_name[] = {"none", "v_fma_f32", "v_mul_f32", "v_xor_b32", "v_mov_b32", "v_pk_mul_f32", "v_pk_fma_f32", "v_mad_u64_u32",
@@ -44,7 +54,8 @@ __global__ __launch_bounds__(512) void kern(float *out, long long *cyc, int iter
     __shared__ __attribute__((aligned(16))) char lds[4096];
     const int w = threadIdx.x >> 6;
     f4 acc0 = (f4){seed, seed, seed, seed}, acc1 = acc0;
-    float a = seed + threadIdx.x, b = seed * 2 + threadIdx.x;
+    float a = seed + threadIdx.x, b = seed * 2 + threadIdx.x; (void)a; (void)b;
+    MB_AB_DECL
     float x[4] = {seed, seed + 1, seed + 2, seed + 3}, y = 0.f;
     f2 p[4] = {{seed, 1.f}, {seed, 2.f}, {seed, 3.f}, {seed, 4.f}}, q = {1.0001f, 0.999f};
     unsigned long long u = 0; unsigned m[4] = {threadIdx.x, 2, 3, 4}; f4 l = {0, 0, 0, 0};
@@ -57,8 +68,8 @@ __global__ __launch_bounds__(512) void kern(float *out, long long *cyc, int iter
 #pragma unroll
         for (int uu = 0; uu < 32; ++uu) {
             if (do_mfma) {
-                if (uu & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc1, 0, 0, 0);
-                else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc0, 0, 0, 0);
+                if (uu & 1) MB_MFMA(acc1);
+                else MB_MFMA(acc0);
             }
             if (do_fill) {
 #pragma unroll
@@ -81,15 +92,16 @@ __global__ __launch_bounds__(256 * W) void kern_c(float *out, long long *cyc, in
 {
     const int w = threadIdx.x >> 6, g = w >> 2;
     f4 acc0 = (f4){seed, seed, seed, seed}, acc1 = acc0;
-    float a = seed + threadIdx.x, b = seed * 2 + threadIdx.x;
+    float a = seed + threadIdx.x, b = seed * 2 + threadIdx.x; (void)a; (void)b;
+    MB_AB_DECL
     float x[4] = {seed, seed + 1, seed + 2, seed + 3};
     // stagger: group g first runs a partial MFMA phase
-    for (int i = 0; i < g * (M / W); i += 2) { acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc1, 0, 0, 0); }
+    for (int i = 0; i < g * (M / W); i += 2) { MB_MFMA(acc0); MB_MFMA(acc1); }
     long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
         if (PRIO == 2) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
-        for (int i = 0; i < M; i += 2) { acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc1, 0, 0, 0); }
+        for (int i = 0; i < M; i += 2) { MB_MFMA(acc0); MB_MFMA(acc1); }
         if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
         if (PRIO == 1) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
