@@ -161,7 +161,7 @@ def comm_ranks_or_none(pl):
         return None
 
 
-def b5_leg(torch, dist, pb, G, rank, dev, native, steps, warmup, rehearse_world=0, ctl_dev=None):
+def b5_leg(torch, dist, pb, G, rank, dev, native, steps, warmup, rehearse_world=0, ctl_dev=None, precision='fp32'):
     """BASELINE.json configs[4], strong-scaled: N = 65536 candidates (K = P = E = 5, H = 30, I = 5, k = 6554) sharded over the G
     ranks of this run, one all-gather of the scores per CEM iteration.  Timed like the headline: barrier + synchronize on both
     sides, max over ranks.  `rehearse_world` = R > 0 (CEM_BENCH_B5_REHEARSAL=R on a one-GPU box): this process plays rank 0 of R —
@@ -173,7 +173,7 @@ def b5_leg(torch, dist, pb, G, rank, dev, native, steps, warmup, rehearse_world=
     W = rehearse_world or G
     cfg = PlannerConfig(obs_dim=obs, act_dim=act, ensemble_size=K, particles=K, n_samples=N, horizon=H, n_elite=k, iterations=I,
                         scorer=pb['scorer'], act_low=pb['low'], act_high=pb['high'], stddev_threshold=-1.0, noise_stddev=1e-3, variant='cem',
-                        world_size=W, rank=0 if rehearse_world else rank, use_graph=not rehearse_world)
+                        world_size=W, rank=0 if rehearse_world else rank, use_graph=not rehearse_world, precision=precision)
     pl = CemPlanner(cfg, device=dev)
     pl.set_weights(pb['weights'])
     pl.set_normaliser(pb['inputs_min'], pb['inputs_max'])
@@ -236,7 +236,8 @@ def b5_leg(torch, dist, pb, G, rank, dev, native, steps, warmup, rehearse_world=
                plans_per_s=steps / dt, ms_per_plan=1e3 * dt / steps, steps=steps, n_ranks=W, candidates_per_rank=N // W,
                candidate_trajectory_steps_per_s=steps / dt * I * N * H,
                rollout_ms_per_launch=avg_ms, rollout_frac_of_fp32_mfma_peak_per_rank=flops_launch / (avg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-               rollout_kernel=rollout_kernel_name(pl, obs, act), select_us_per_iteration=1e3 * sel_ms / max(roll_n, 1),
+               rollout_kernel=(rollout_kernel_name(pl, obs, act) if precision == 'fp32' else 'void cem_rollout_split_kernel<%d, 1, 0>(RolloutParams)' % pl.tiles()[0]),
+               precision=precision, select_us_per_iteration=1e3 * sel_ms / max(roll_n, 1),
                chunks_per_tile=pl.tiles()[0], tiles=int(len(pl.tiles()[1])), exchange=exchange, n_ranks_seen_by_rccl=n_seen,
                hip_graph=pl.graph_status() == 'graph')
     if native and not rehearse_world:
@@ -413,6 +414,9 @@ def main():
             pl.comm_destroy()                          # one communicator at a time
         out['b5'] = b5_leg(torch, dist, pb, G, rank, dev, native, steps=min(args.steps, 20), warmup=min(max(args.warmup, 2), 5),
                            rehearse_world=rehearse if G == 1 else 0, ctl_dev=ctl_dev)
+        if not args.no_split_leg:                      # the same sharded plan on the opt-in split-product rollout: a labelled extra, never `value`
+            out['b5_split_bf16x3'] = b5_leg(torch, dist, pb, G, rank, dev, native, steps=min(args.steps, 20), warmup=min(max(args.warmup, 2), 5),
+                                            rehearse_world=rehearse if G == 1 else 0, ctl_dev=ctl_dev, precision='bf16x3')
     if G == 1 and not distributed and not args.no_split_leg:
         out['split_bf16x3'] = split_leg(torch, pb, dev, steps=min(args.steps, 50), warmup=min(max(args.warmup, 3), 10), n_per_gpu=args.n_per_gpu)
     if rank == 0 and G == 1 and not args.no_cpu_baseline:

@@ -99,3 +99,5 @@ def test_bench_multi_rank_leg_two_ranks_on_one_gpu(fake_rccl):
     assert d['config']['hip_graph'] is True
     assert d['value'] > 0 and d['b5']['n_ranks'] == 2 and d['b5']['candidates_per_rank'] == 32768 and d['b5']['n_ranks_seen_by_rccl'] == 2
     assert d['b5']['exchange'].startswith('ncclAllGather inside the library') and d['b5']['hip_graph'] is True
+    sp = d['b5_split_bf16x3']
+    assert sp['precision'] == 'bf16x3' and sp['n_ranks'] == 2 and sp['hip_graph'] is True and sp['plans_per_s'] > 0
