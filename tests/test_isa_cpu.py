@@ -79,3 +79,34 @@ def test_fused_select_grid_barrier_drains_before_arriving(isa):
         assert a - bar < 20, (a, bar)
         prev = ins[max(0, bar - 3):bar]
         assert any(x.startswith('s_waitcnt') and 'vmcnt(0)' in x for x in prev), (a, prev)
+
+
+def _kernel_meta(isa, pattern):
+    """{mangled name: {vgpr_count, vgpr_spill_count, private_segment_fixed_size}} from the code-object metadata."""
+    out = {}
+    for m in re.finditer(r'\.name:\s+(_Z\w+)\s*\n(.*?)(?=\n\s+- \.|\namdhsa\.target|\Z)', isa, re.S):
+        if re.search(pattern, m.group(1)):
+            d = {}
+            for k in ('vgpr_count', 'vgpr_spill_count', 'private_segment_fixed_size'):
+                mm = re.search(r'\.%s:\s+(\d+)' % k, m.group(0))
+                d[k] = int(mm.group(1)) if mm else None
+            out[m.group(1)] = d
+    return out
+
+
+def test_split_rollout_kernels_fit_the_residency_their_tile_rule_assumes(isa):
+    """cem_rollout_split_kernel (planning instantiations): no scratch, no spilled VGPRs, the products really are bf16 MFMAs, and the
+    register counts the automatic tile sizes rest on (make_plan: up to 3 chunks at obs+act <= 64, 2 above — two resident workgroups,
+    i.e. at most 256 VGPRs; a one-chunk tile of the small family keeps three, at most 170)."""
+    meta = _kernel_meta(isa, r'cem_rollout_split_kernelILi\dELi\dELi0EE')
+    assert len(meta) == 8, sorted(meta)
+    for name, d in meta.items():
+        rc, nfw = int(re.search(r'ILi(\d)ELi(\d)E', name).group(1)), int(re.search(r'ILi(\d)ELi(\d)E', name).group(2))
+        if (nfw == 1 and rc <= 3) or (nfw == 2 and rc <= 2):          # the sizes make_plan picks by itself
+            assert d['vgpr_spill_count'] == 0 and d['private_segment_fixed_size'] == 0, (name, d)
+            assert d['vgpr_count'] <= (170 if (rc, nfw) == (1, 1) else 256), (name, d)
+    m = re.search(r'^(_Z24cem_rollout_split_kernelILi1ELi1ELi0EEv13RolloutParams):.*?\n(.*?)^\.Lfunc_end', isa, re.M | re.S)   # (the kernel has an early s_endpgm)
+    ins = [l.split(';')[0].strip() for l in m.group(2).splitlines() if l.strip() and not l.lstrip().startswith((';', '.'))]
+    assert sum(1 for l in ins if l.startswith('v_mfma_f32_16x16x32_bf16')) >= 12 * (2 + 4 + 4), 'six products x two output blocks per chunk'
+    assert not any(l.startswith('v_mfma_f32_16x16x4_f32') for l in ins), 'the split kernel must not fall back to fp32 MFMAs'
+    assert any(l.startswith('v_cvt_pk_bf16_f32') for l in ins), 'the split rounds to nearest with the hardware conversion'
