@@ -31,7 +31,7 @@ with open(os.path.join(out, 'summary_pmc.csv'), 'w') as fh:
         fh.write('"%s",%s,%d,%g,%s\n' % r)
 # ONE kernel's counters: the rollout instantiation of the profiled workload (the fp32 headline path; a run that also launched the
 # opt-in split kernel or another instantiation must not mix their rows in)
-kern = next((k for k, c, n, m, p in rows if 'cem_rollout_' in k and 'split' not in k), None)
+kern = next((k for k, c, n, m, p in rows if 'cem_rollout_' in k and 'split' not in k), None) or next((k for k, c, n, m, p in rows if 'cem_rollout_' in k), None)
 roll = {c: m for k, c, n, m, p in rows if k == kern}
 if roll:
     hit, miss = roll.get('TCC_HIT_sum', 0.0), roll.get('TCC_MISS_sum', 0.0)
