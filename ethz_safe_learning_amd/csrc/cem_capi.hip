@@ -29,7 +29,7 @@ struct Dims {
     int Nloc, n_off, Bloc, Btot;
     int KB_in, KB_obs, NFW, KF0;     // KF0 = 4*NFW: layer-0 groups per wave, zero padded so every stage is a multiple of 4
     int act_q0, act_nq;              // feature quads of the network input that hold action features: [act_q0, act_q0 + act_nq)
-    bool wide;                       // units > 128: the width-generic rollout kernel on the natural weight blob (cem_rollout_wide.h)
+    bool wide;                       // units > 128 or an activation other than relu: the generic rollout kernel (cem_rollout_wide.h)
     bool split;                      // precision CEM_PRECISION_SPLIT_BF16X3: cem_rollout_split.h (weight stream in 6 KB chunk groups)
     int wave_groups[4]; uint32_t wave_off_f4[4]; uint32_t member_stride_f4;
     size_t nat_member_floats;

@@ -50,8 +50,8 @@ enum cem_status {
 enum cem_variant { CEM_VARIANT_CEM = 0 /* CemMpc */, CEM_VARIANT_SAFE = 1 /* SafeCemMpc */ };
 
 /* mlp_params['activation'] of config/models.yaml:12, which the reference `eval`s (mlp_ensemble.py:14): the hidden layers'
- * nonlinearity.  relu (the shipped value) runs on the tuned kernels; the others on the width-generic rollout kernel and the
- * GEMM-by-GEMM trainer (functional paths).  tf.nn.elu: alpha 1; tf.nn.leaky_relu: alpha 0.2 (TensorFlow's defaults). */
+ * nonlinearity.  relu (the shipped value) runs on the tuned kernels; the others on the generic rollout kernel and the
+ * GEMM-by-GEMM trainer.  tf.nn.elu: alpha 1; tf.nn.leaky_relu: alpha 0.2 (TensorFlow's defaults). */
 enum cem_activation { CEM_ACT_RELU = 0, CEM_ACT_TANH = 1, CEM_ACT_SIGMOID = 2, CEM_ACT_ELU = 3, CEM_ACT_LEAKY_RELU = 4, CEM_ACT_SOFTPLUS = 5 };
 
 /* SafetyGymStateScorer fields used by the 'goal' task (safety_gym.py:104-176).
@@ -89,8 +89,8 @@ typedef struct cem_config {
     int32_t abi_version;          /* CEM_ABI_VERSION */
     int32_t obs_dim, act_dim;
     int32_t units, n_layers;      /* mlp_params: units <= 128 run on the fast kernels (narrower layers zero-padded to the 128-wide form:
-                                   * exactly the narrow network's result); 129..256 on width-generic kernels (same semantics, the natural
-                                   * weight blob read in place; a functional path, not a tuned one) */
+                                   * exactly the narrow network's result); 129..256 — and any activation other than relu — on the generic
+                                   * kernels (same semantics; cem_rollout_wide.h) */
     int32_t activation;           /* enum cem_activation */
     int32_t ensemble_size;        /* E */
     int32_t particles;            /* P */
