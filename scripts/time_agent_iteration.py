@@ -26,6 +26,8 @@ def main():
     env = make_environment(params, seed=1)
     for p in params['policies'].values():
         p.setdefault('seed', 1)
+        if os.environ.get('CEM_AGENT_PRECISION'):          # 'bf16x3': the opt-in split-product rollout (a policy kwarg beyond the reference's)
+            p['precision'] = os.environ['CEM_AGENT_PRECISION']
     agent = make_agent(params, env)
     agent.build_graph()
     clock = dict(plan=0.0, fit=0.0, plans=0, fits=0)
