@@ -609,7 +609,10 @@ int cem_pack_weights_host(const cem_config_t *cfg, const float *blob, float *pac
     if (!blob || !packed) return CEM_ERR_INVALID_ARG;
     const Dims d = make_dims(cfg);
     if (d.wide) return CEM_ERR_UNSUPPORTED;
-    for (int m = 0; m < d.E; ++m) pack_member(d, blob + (size_t)m * d.nat_member_floats, packed + (size_t)m * d.member_stride_f4 * 4);
+    for (int m = 0; m < d.E; ++m) {
+        if (d.split) pack_member_split(d, blob + (size_t)m * d.nat_member_floats, reinterpret_cast<uint16_t *>(packed + (size_t)m * d.member_stride_f4 * 4));
+        else pack_member(d, blob + (size_t)m * d.nat_member_floats, packed + (size_t)m * d.member_stride_f4 * 4);
+    }
     return CEM_OK;
 }
 

@@ -83,3 +83,77 @@ def test_dot_products_of_split_operands_match_fp32_dot_products():
     scale = np.abs(W.astype(np.float64) * X.astype(np.float64)).sum(axis=1)
     e_split, e_plain = np.abs(acc - exact) / scale, np.abs(plain - exact) / scale
     assert e_split.max() <= 4e-7 and e_split.max() <= 2.0 * max(e_plain.max(), 6e-8), (e_split.max(), e_plain.max())
+
+
+# ---- the packed weight stream of the split kernel (pack_member_split), consumed the way cem_rollout_split.h consumes it ----------------
+def _bf16_planes_to_f64(words16):
+    return (np.asarray(words16, np.uint32) << 16).view(np.float32).astype(np.float64)
+
+
+def _perm(w, phi):                                        # cem_split_perm
+    return w if phi == 0 else (phi - 1 if phi - 1 < w else phi)
+
+
+import pytest
+
+
+@pytest.mark.parametrize('obs_dim,act_dim,n_layers,units', [(60, 2, 4, 128), (100, 12, 3, 128), (23, 3, 2, 48), (64, 2, 2, 128)])
+def test_split_weight_stream_reproduces_the_network(obs_dim, act_dim, n_layers, units):
+    """Every 6 KB group of every wave's stream, read with the lane map of v_mfma_f32_16x16x32_bf16 (lane 16 q + i: output feature
+    16 G + i, k slots s = 0..7 = input features 16 (2 F + s / 4) + 4 q + s % 4), holds the three bf16 pieces of exactly the weight the
+    kernel multiplies there — their sum is the fp32 weight bit for bit — in the order the kernel visits the chunks (layer 0 ascending,
+    hidden / heads stages own chunk first), and one step consumes the whole stream once."""
+    from ethz_safe_learning_amd import PlannerConfig, ScorerConfig, pack_weights_host
+    from oracle import cem_oracle as o
+    E = 2
+    pb = o.synthetic_problem(obs_dim=obs_dim, act_dim=act_dim, ensemble_size=E, units=units, n_layers=n_layers, seed=11)
+    cfg = PlannerConfig(obs_dim=obs_dim, act_dim=act_dim, ensemble_size=E, particles=2, n_samples=64, horizon=4, n_elite=4, iterations=2,
+                        n_layers=n_layers, units=units, scorer=ScorerConfig(goal_slice=(0, 2)), act_low=[-1] * act_dim, act_high=[1] * act_dim,
+                        precision='bf16x3')
+    packed = pack_weights_host(cfg, pb['weights']).view(np.uint16)
+    D = obs_dim + act_dim
+    nfw = ((D + 15) // 16 + 3) // 4
+    kb_obs = (obs_dim + 15) // 16
+    nch0 = 2 * nfw
+    groups = [nch0 + 4 * (n_layers - 1) + 4 * sum(1 for i in range(nfw) if w + 4 * i < kb_obs) for w in range(4)]
+    stride16 = packed.size // E
+    assert stride16 >= sum(groups) * 3072
+    lane = np.arange(64); qq, ii = lane >> 4, lane & 15
+    for m in range(E):
+        wts = pb['weights'][m]
+        pos = m * stride16
+        for w in range(4):
+            def check(W, in_dim, out_dim, F, Ga, Gb):
+                nonlocal pos
+                g = packed[pos:pos + 3072].reshape(6, 64, 8)
+                for ab, G in ((0, Ga), (1, Gb)):
+                    val = sum(_bf16_planes_to_f64(g[3 * ab + pl]) for pl in range(3))          # [64 lanes][8 slots]
+                    for s in range(8):
+                        k = 16 * (2 * F + (s >> 2)) + 4 * qq + (s & 3)
+                        oo = 16 * G + ii
+                        ok = (k < in_dim) & (oo < out_dim)
+                        ref = np.where(ok, W[np.minimum(k, in_dim - 1), np.minimum(oo, out_dim - 1)].astype(np.float64), 0.0)
+                        np.testing.assert_array_equal(val[:, s], ref)
+                pos += 3072
+            for P in range(nch0):
+                check(wts['W'][0], D, units, P, 2 * w, 2 * w + 1)
+            for l in range(1, n_layers):
+                for P in range(4):
+                    check(wts['W'][l], units, units, _perm(w, P), 2 * w, 2 * w + 1)
+            for i in range(nfw):
+                Fo = w + 4 * i
+                if Fo >= kb_obs:
+                    continue
+                for P in range(4):
+                    F = _perm(w, P)
+                    g = packed[pos:pos + 3072].reshape(6, 64, 8)
+                    for ab, Wh in ((0, wts['W_mu']), (1, wts['W_var'])):
+                        val = sum(_bf16_planes_to_f64(g[3 * ab + pl]) for pl in range(3))
+                        for s in range(8):
+                            k = 16 * (2 * F + (s >> 2)) + 4 * qq + (s & 3)
+                            oo = 16 * Fo + ii
+                            ok = (k < units) & (oo < obs_dim)
+                            ref = np.where(ok, Wh[np.minimum(k, units - 1), np.minimum(oo, obs_dim - 1)].astype(np.float64), 0.0)
+                            np.testing.assert_array_equal(val[:, s], ref)
+                    pos += 3072
+            assert pos - m * stride16 == sum(groups[:w + 1]) * 3072
