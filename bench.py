@@ -143,11 +143,61 @@ def cpu_baseline(budget_s=25.0):
         res[name] = dict(plans_per_s=1.0 / float(np.median(times)), plans_timed=len(times), median_s=float(np.median(times)),
                          workload='obs=60 act=2 K=P=E=5 N=%d H=%d I=5 k=N/10' % (N, H))
     torch.set_num_threads(default_threads)
+    torch_leg = dict(value=res['B2']['plans_per_s'], unit='plans/s', cores=int(threads), kind='port', host_cpu_count=os.cpu_count(),
+                     torch_num_threads=int(threads), torch_default_threads=int(default_threads),
+                     thread_trial_b1_seconds={str(k): round(v, 3) for k, v in trial.items()},
+                     sample='median of %d whole B2 plans (N=2000,H=30,K=5,I=5) after 1 warm-up through oracle/cem_oracle_fast.py '
+                            '(torch-CPU fp32, baddbmm over members, %d intra-op threads — the fastest of a short trial — of %s host CPUs); B1 (N=500,H=25): median of %d plans'
+                            % (res['B2']['plans_timed'], threads, os.cpu_count(), res['B1']['plans_timed']),
+                     b1=res['B1'], b2=res['B2'])
+    # The same plan through the C + OpenMP restatement (oracle/cem_oracle_c.c, pinned to the numpy oracle by tests/test_oracle_c.py): the
+    # faster of the two is the reported baseline, both are in the line.
+    try:
+        c_leg = cpu_baseline_openmp(pb, osp, o, budget_s)
+    except Exception as e:                                  # no gcc / OpenMP on this box: the torch port stands alone
+        c_leg = dict(error=str(e)[:200])
+    best = dict(c_leg if c_leg.get('value', 0.0) > torch_leg['value'] else torch_leg)
+    best['torch_port'] = {k: torch_leg[k] for k in ('value', 'cores', 'sample', 'thread_trial_b1_seconds', 'b1', 'b2')}
+    best['c_openmp'] = c_leg
+    return best
+
+
+def cpu_baseline_openmp(pb, osp, o, budget_s):
+    """oracle/cem_oracle_c.c on this box's host cores: noise drawn inside the plan (per-thread generator), thread count = the fastest of
+    a short trial on B1, then the median of >= 3 whole plans of B1 and B2."""
+    from oracle import cem_oracle_c as oc                   # cpu_baseline leg only
+    I, K = 5, 5
+
+    def run_plan(N, H, seed):
+        cfg = o.PlanConfig(horizon=H, iterations=I, n_samples=N, n_elite=N // 10, particles=K, ensemble_size=K, stddev_threshold=-1.0, noise_stddev=1e-3)
+        t0 = time.perf_counter()
+        a, s, it = oc.do_generate_action(pb['state'], pb['weights'], pb['inputs_min'], pb['inputs_max'], pb['low'], pb['high'], None, None, None, cfg, osp, seed=seed)
+        dt = time.perf_counter() - t0
+        assert it == I and np.all(np.isfinite(a))
+        return dt
+    trial = {}
+    top = max(oc.max_threads(), 1)
+    for th in sorted({t for t in (4, 8, 16, 32, 64, 128, top) if t <= max(top, 4)}):
+        oc.set_threads(th)
+        run_plan(500, 25, 1)
+        trial[th] = run_plan(500, 25, 2)
+        if trial[th] > 2.0 * min(trial.values()):
+            break
+    threads = min(trial, key=trial.get)
+    oc.set_threads(threads)
+    res = {}
+    for name, N, H, share in (('B1', 500, 25, 0.15), ('B2', 2000, 30, 0.35)):
+        times = []
+        t_start = time.perf_counter()
+        while len(times) < 4 or (time.perf_counter() - t_start < budget_s * share and len(times) < 41):
+            times.append(run_plan(N, H, 10 + len(times)))
+        times = times[1:]
+        res[name] = dict(plans_per_s=1.0 / float(np.median(times)), plans_timed=len(times), median_s=float(np.median(times)),
+                         workload='obs=60 act=2 K=P=E=5 N=%d H=%d I=5 k=N/10' % (N, H))
     return dict(value=res['B2']['plans_per_s'], unit='plans/s', cores=int(threads), kind='port', host_cpu_count=os.cpu_count(),
-                torch_num_threads=int(threads), torch_default_threads=int(default_threads),
                 thread_trial_b1_seconds={str(k): round(v, 3) for k, v in trial.items()},
-                sample='median of %d whole B2 plans (N=2000,H=30,K=5,I=5) after 1 warm-up through oracle/cem_oracle_fast.py '
-                       '(torch-CPU fp32, baddbmm over members, %d intra-op threads — the fastest of a short trial — of %s host CPUs); B1 (N=500,H=25): median of %d plans'
+                sample='median of %d whole B2 plans (N=2000,H=30,K=5,I=5) after 1 warm-up through oracle/cem_oracle_c.c (plain C, fp32, OpenMP over '
+                       '16-row blocks, %d threads — the fastest of a short trial — of %s host CPUs); B1 (N=500,H=25): median of %d plans'
                        % (res['B2']['plans_timed'], threads, os.cpu_count(), res['B1']['plans_timed']),
                 b1=res['B1'], b2=res['B2'])
 
