@@ -97,18 +97,34 @@ static size_t member_floats(const cem_c_config *c)
     return D * U + U + (size_t)(c->L - 1) * (U * U + U) + 2 * (U * O + O);
 }
 
-/* out[r][j] = bias[j] + sum_k in[r][k] W[k][j], k ascending */
+/* out[r][j] = bias[j] + sum_k in[r][k] W[k][j], k ascending for every element (register tile of 4 rows x 16 columns: the weights of a k are
+ * loaded once for four rows and the partial sums never leave the registers; the order of additions per element is unchanged) */
+#define TR 4
+#define TJ 16
 static void dense(const float *in, int ldi, int K, const float *W, const float *b, int J, float *out, int ldo, int rows)
 {
-    for (int r = 0; r < rows; ++r) {
-        float *o = out + (size_t)r * ldo;
-        for (int j = 0; j < J; ++j) o[j] = b[j];
-        const float *x = in + (size_t)r * ldi;
-        for (int k = 0; k < K; ++k) {
-            const float a = x[k];
-            const float *w = W + (size_t)k * J;
+    for (int r0 = 0; r0 < rows; r0 += TR) {
+        const int nr = rows - r0 < TR ? rows - r0 : TR;
+        for (int j0 = 0; j0 < J; j0 += TJ) {
+            const int nj = J - j0 < TJ ? J - j0 : TJ;
+            float acc[TR][TJ];
+            for (int r = 0; r < TR; ++r)
+                for (int j = 0; j < TJ; ++j) acc[r][j] = j < nj ? b[j0 + j] : 0.f;
+            if (nr == TR && nj == TJ) {
+                for (int k = 0; k < K; ++k) {
+                    const float *w = W + (size_t)k * J + j0;
+                    const float a0 = in[(size_t)(r0 + 0) * ldi + k], a1 = in[(size_t)(r0 + 1) * ldi + k], a2 = in[(size_t)(r0 + 2) * ldi + k], a3 = in[(size_t)(r0 + 3) * ldi + k];
 #pragma omp simd
-            for (int j = 0; j < J; ++j) o[j] += a * w[j];
+                    for (int j = 0; j < TJ; ++j) { const float wv = w[j]; acc[0][j] += a0 * wv; acc[1][j] += a1 * wv; acc[2][j] += a2 * wv; acc[3][j] += a3 * wv; }
+                }
+            } else {
+                for (int k = 0; k < K; ++k) {
+                    const float *w = W + (size_t)k * J + j0;
+                    for (int r = 0; r < nr; ++r) { const float a = in[(size_t)(r0 + r) * ldi + k]; for (int j = 0; j < nj; ++j) acc[r][j] += a * w[j]; }
+                }
+            }
+            for (int r = 0; r < nr; ++r)
+                for (int j = 0; j < nj; ++j) out[(size_t)(r0 + r) * ldo + j0 + j] = acc[r][j];
         }
     }
 }
