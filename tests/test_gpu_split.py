@@ -168,3 +168,27 @@ def test_b1_reference_scale_plan_on_the_split_kernel():
     assert it == rit and abs(s - rs) <= 2e-5, (s, rs)
     np.testing.assert_allclose(a, ra, rtol=1e-5, atol=1e-6)
     pl.close()
+
+
+def test_unfold_sequences_large_batch_uses_two_chunk_tiles_on_both_precisions():
+    """cem_unfold_sequences picks two-chunk tiles from 8192 rows on: the split and the fp32 kernels must still agree row for row."""
+    import torch
+    pb = hp.make_problem(60, 2, 5, 4, seed=2)
+    rng = np.random.default_rng(6)
+    B, H = 8200, 3
+    s0 = rng.normal(0, 0.3, (B, 60)).astype(np.float32)
+    acts = rng.uniform(-1, 1, (B, H, 2)).astype(np.float32)
+    eps = rng.standard_normal((H, B, 60)).astype(np.float32)
+    out = {}
+    for prec in ('fp32', 'bf16x3'):
+        _, pcfg = hp.configs(pb, N=64, H=4, P=5, E=5, k=6, I=1, precision=prec)
+        pl = hp.make_planner(pb, pcfg)
+        out[prec] = pl.unfold_sequences(s0, acts, eps_model=eps).cpu().numpy()
+        torch.cuda.synchronize()
+        pl.close()
+    np.testing.assert_allclose(out['fp32'], out['bf16x3'], rtol=1e-5, atol=1e-5)
+    members = np.arange(B) // (B // 5)
+    sub = rng.choice(B, 64, replace=False)
+    ref = o.unfold_sequences(s0[sub].astype(np.float64), acts[sub].astype(np.float64), o.cast_weights(pb['weights'], np.float64), members[sub],
+                             pb['inputs_min'], pb['inputs_max'], eps[:, sub])
+    np.testing.assert_allclose(out['bf16x3'][sub], ref, rtol=2e-5, atol=2e-5)
