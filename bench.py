@@ -465,10 +465,16 @@ def main():
         out['b5'] = b5_leg(torch, dist, pb, G, rank, dev, native, steps=min(args.steps, 20), warmup=min(max(args.warmup, 2), 5),
                            rehearse_world=rehearse if G == 1 else 0, ctl_dev=ctl_dev)
         if not args.no_split_leg:                      # the same sharded plan on the opt-in split-product rollout: a labelled extra, never `value`
-            out['b5_split_bf16x3'] = b5_leg(torch, dist, pb, G, rank, dev, native, steps=min(args.steps, 20), warmup=min(max(args.warmup, 2), 5),
-                                            rehearse_world=rehearse if G == 1 else 0, ctl_dev=ctl_dev, precision='bf16x3')
+            try:
+                out['b5_split_bf16x3'] = b5_leg(torch, dist, pb, G, rank, dev, native, steps=min(args.steps, 20), warmup=min(max(args.warmup, 2), 5),
+                                                rehearse_world=rehearse if G == 1 else 0, ctl_dev=ctl_dev, precision='bf16x3')
+            except Exception as e:                         # an extra must never cost the run its headline line
+                out['b5_split_bf16x3'] = {'error': str(e)[:300]}
     if G == 1 and not distributed and not args.no_split_leg:
-        out['split_bf16x3'] = split_leg(torch, pb, dev, steps=min(args.steps, 50), warmup=min(max(args.warmup, 3), 10), n_per_gpu=args.n_per_gpu)
+        try:
+            out['split_bf16x3'] = split_leg(torch, pb, dev, steps=min(args.steps, 50), warmup=min(max(args.warmup, 3), 10), n_per_gpu=args.n_per_gpu)
+        except Exception as e:                             # an extra must never cost the run its headline line
+            out['split_bf16x3'] = {'error': str(e)[:300]}
     if rank == 0 and G == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     if rank == 0:
