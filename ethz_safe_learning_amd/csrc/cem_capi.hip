@@ -404,6 +404,28 @@ int auto_chunks(const Dims &d, int requested_segments)
     return best;
 }
 
+// Tile size of the split-product rollout (cem_rollout_split.h).  It streams 1.5x the weight bytes at 2.7x the matrix rate, so one-chunk
+// tiles are bound by the L2 -> CU path and larger tiles pay; what decides between the sizes is how many tiles the busiest CU gets
+// (ceil(tiles / CUs)) and how many of them run side by side.  K cycles per step of ONE CU running m co-resident tiles of rc chunks,
+// measured over population sizes (scripts/sweep_split_tiles.py, profiles/r03_split_tile_sizes.txt); residency: registers / LDS.
+static const double kSplitStep[2][4][3] = {{{11.2, 18.2, 28.5}, {15.8, 25.0, 0}, {21.6, 34.2, 0}, {27.2, 0, 0}},
+                                           {{14.2, 26.0, 0}, {21.0, 39.0, 0}, {28.5, 0, 0}, {36.4, 0, 0}}};
+static const int kSplitResident[2][4] = {{3, 2, 2, 1}, {2, 2, 1, 1}};
+int auto_chunks_split(const Dims &d)
+{
+    int best = 1; double bestc = 1e30;
+    for (int rc = 1; rc <= 4; ++rc) {
+        std::vector<Tile6> t; build_plan_tiles(d, rc, t);
+        const long per_cu = (long)((t.size() + num_cus() - 1) / num_cus());
+        const int R = kSplitResident[d.NFW - 1][rc - 1];
+        const double *ts = kSplitStep[d.NFW - 1][rc - 1];
+        const double cost = (double)(per_cu / R) * ts[R - 1] + (per_cu % R ? ts[per_cu % R - 1] : 0.0);
+        // rc ascends: within 5 % the larger tile wins (fewer workgroups, a third or half of the weight traffic)
+        if (cost <= bestc * 1.05) { best = rc; bestc = std::min(bestc, cost); }
+    }
+    return best;
+}
+
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
@@ -419,15 +441,7 @@ Plan make_plan(const cem_config_t *c, const Dims &d)
 {
     Plan pl{};
     pl.rc = d.wide ? 1 : (c->chunks_per_tile ? c->chunks_per_tile : auto_chunks(d, c->rollout_segments));   // the wide kernel: 16-row tiles
-    if (d.split && !c->chunks_per_tile) {
-        // The split kernel streams 1.5x the weight bytes at 2.7x the matrix rate: one-chunk tiles are bound by the L2 -> CU path
-        // (64 B per clock per CU: 438 KB per tile-step = 6.8 K cycles against 3.5 K of MFMA), so a tile takes as many chunks as the
-        // population has per CU, up to what keeps two workgroups resident (3 at obs+act <= 64: 218 VGPRs / 77 KB LDS; 2 above:
-        // 229 VGPRs).  Measured (profiles/r03_split_tile_sizes.txt): B1 1, B2 3, B3 3, B4 2, B5 rank 3.
-        std::vector<Tile6> t1; build_plan_tiles(d, 1, t1);
-        const int per_cu = (int)((t1.size() + num_cus() - 1) / num_cus());
-        pl.rc = std::max(1, std::min(per_cu, d.NFW == 1 ? 3 : 2));
-    }
+    if (d.split && !c->chunks_per_tile) pl.rc = auto_chunks_split(d);
     std::vector<Tile6> t; build_plan_tiles(d, pl.rc, t);
     pl.n_tiles = (int)t.size();
     pl.n_seg = (d.wide || d.split) ? 1 : segments_for(d, pl.rc, t.size(), c->rollout_segments);
