@@ -1,4 +1,6 @@
 """Shared builders for the parity tests: one synthetic problem -> (oracle config, planner config)."""
+import os
+
 import numpy as np
 
 from oracle import cem_oracle as o
@@ -22,6 +24,9 @@ def configs(pb, N, H, P, E, k, I=3, variant='cem', thr=-1.0, noise=0.0, post=0.3
             sampling=True, scale=True, world_size=1, rank=0, chunks_per_tile=0, use_graph=False, rollout_segments=0, select_mode=0, precision='fp32'):
     sp = pb['scorer']
     O, A = pb['state'].shape[0], pb['low'].shape[0]
+    # CEM_TEST_PRECISION=bf16x3: run every eligible case (units <= 128, relu) of the suites on the split-product rollout (a one-off coverage run)
+    if os.environ.get('CEM_TEST_PRECISION') and pb['weights'][0]['W'][0].shape[1] <= 128 and pb['weights'][0].get('activation', 'relu') == 'relu':
+        precision = os.environ['CEM_TEST_PRECISION']
     ocfg = o.PlanConfig(horizon=H, iterations=I, n_samples=N, n_elite=k, particles=P, ensemble_size=E, smoothing=smoothing,
                         stddev_threshold=thr, noise_stddev=noise, variant=variant, posterior_mean_threashold=post,
                         scale_features=scale, sampling_propagation=sampling)
