@@ -1036,7 +1036,7 @@ int enqueue_select(cem_planner *h, int it)
     p.stamps = (long long *)(ws + l.stamps) + 64;          // past tile 0's rollout stamps; written by -DCEM_STAMPS builds only
     size_t lds = (size_t)((d.k + 3) & ~3) * 4 + (size_t)2 * d.H * d.A * 4;
     const size_t dyn_limit = h->sel_dyn_limit;          // asked from the runtime at create(), per device
-    const bool cache = lds + (size_t)d.N * 4 <= dyn_limit;
+    const bool cache = lds + (size_t)CEM_SEL_KWORDS(d.N) * 4 <= dyn_limit;
     // Large populations (the replicated select of a many-GPU plan) go through multi-workgroup kernels (cem_mpc.h select_mode):
     // the fused form (one launch, grid barriers) whenever all its ceil(N / 4096) workgroups are resident at once, the eight-launch
     // chain beyond that (more workgroups than CUs), the one-workgroup kernel for populations it still serves faster.  Measured
@@ -1075,7 +1075,7 @@ int enqueue_select(cem_planner *h, int it)
             hipLaunchKernelGGL(cem_msel_final_kernel, dim3(1), dim3(256), 0, h->stream, m);
         }
     } else {
-        if (cache) lds += (size_t)d.N * 4;
+        if (cache) lds += (size_t)CEM_SEL_KWORDS(d.N) * 4;
         if (cache) hipLaunchKernelGGL(cem_select_kernel<true>, dim3(1), dim3(1024), lds, h->stream, p);
         else hipLaunchKernelGGL(cem_select_kernel<false>, dim3(1), dim3(1024), lds, h->stream, p);
     }

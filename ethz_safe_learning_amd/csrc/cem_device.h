@@ -1100,6 +1100,8 @@ struct SelectParams {
 #define CEM_SEL_STAMP(i) do { } while (0)
 #endif
 
+#define CEM_SEL_KIDX(i) ((i) + ((i) >> 5))        // LDS word of key i in the one-workgroup select's staged key list (one pad word per 32 keys)
+#define CEM_SEL_KWORDS(n) ((n) + ((n) >> 5) + 1)    // words that list takes
 __device__ __forceinline__ uint32_t cem_f2key(float f)
 {
     const uint32_t u = __float_as_uint(f);
@@ -1169,7 +1171,10 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
     int32_t *elite = reinterpret_cast<int32_t *>(sel_smem);                 // [k]
     float *colmean = reinterpret_cast<float *>(sel_smem + (size_t)((k + 3) & ~3) * 4);   // [HA]
     float *newsig = colmean + HA;                                           // [HA] smoothed sigma
-    uint32_t *ckey = reinterpret_cast<uint32_t *>(newsig + HA);             // [N] order-preserving keys of the scores (CACHE)
+    // [N + N / 32 + 1] order-preserving keys of the scores (CACHE), key i at word CEM_SEL_KIDX(i) = i + i / 32: the compaction walks a
+    // thread's own run of C = N / 1024 consecutive keys, i.e. the lanes of a wave read words C apart — with C = 16 (N = 16 000) two LDS banks
+    // for all 64 lanes; one pad word per 32 keys spreads them over all banks (compaction 8.4 -> 2 us at N = 16 000)
+    uint32_t *ckey = reinterpret_cast<uint32_t *>(newsig + HA);
 
     // old mu / sigma of the columns this thread will finish (first column block): requested now, needed at the very end
     float old_mu = 0.f, old_sg = 0.f;
@@ -1186,7 +1191,7 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int i = i0 + j * 1024 + tid;
-                if (i < N) { const uint32_t key = cem_f2key(v[j]); ckey[i] = key; kmin = key < kmin ? key : kmin; kmax = key > kmax ? key : kmax; }
+                if (i < N) { const uint32_t key = cem_f2key(v[j]); ckey[CEM_SEL_KIDX(i)] = key; kmin = key < kmin ? key : kmin; kmax = key > kmax ? key : kmax; }
             }
         }
 #pragma unroll
@@ -1196,7 +1201,7 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
         }
         if ((tid & 63) == 0) { wsum[0][tid >> 6] = kmin; wsum[1][tid >> 6] = kmax; }
     }
-    auto K = [&](const int i) { return CACHE ? ckey[i] : cem_f2key(p.scores[i]); };
+    auto K = [&](const int i) { return CACHE ? ckey[CEM_SEL_KIDX(i)] : cem_f2key(p.scores[i]); };
     if (tid < 256) hist[1][tid] = 0;                  // pass 3 counts into hist[3 & 1]
     __syncthreads();
     uint32_t kdiff = 0xFFFFFFFFu;
@@ -1278,7 +1283,7 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
     {
         float bs = -__builtin_inff(); int bp = 0x7fffffff;
         for (int e = tid; e < k; e += 1024) {
-            const float sc = CACHE ? cem_key2f(ckey[elite[e]]) : p.scores[elite[e]];
+            const float sc = CACHE ? cem_key2f(ckey[CEM_SEL_KIDX(elite[e])]) : p.scores[elite[e]];
             if (bp == 0x7fffffff || sc > bs) { bs = sc; bp = e; }
         }
 #pragma unroll
