@@ -9,7 +9,7 @@ res = {l: [] for l in libs}
 for r in range(rounds):
     for l in libs:
         env = dict(os.environ, CEM_MPC_LIB=os.path.abspath(l))
-        out = subprocess.run([sys.executable, 'bench.py', '--steps', '60', '--warmup', '5', '--no-cpu-baseline', '--chunks', chunks],
+        out = subprocess.run([sys.executable, 'bench.py', '--steps', '60', '--warmup', '5', '--no-cpu-baseline', '--no-split-leg', '--chunks', chunks],
                              env=env, capture_output=True, text=True).stdout.strip().splitlines()
         d = json.loads(out[-1])
         res[l].append((d['roofline']['avg_launch_ms'], d['value']))
