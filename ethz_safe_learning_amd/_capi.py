@@ -87,6 +87,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError('HIP extension %s is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
                           'or `make -C ethz_safe_learning_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
+    # The planner's device memory comes from torch, whose wheel carries its own libamdhip64.so.7; the library must bind to THAT
+    # runtime.  Loaded before torch it would pull in /opt/rocm's copy through its RUNPATH, torch would then load its own beside it,
+    # and every pointer torch hands over would be foreign to the runtime the kernels are launched with (cem_planner_create:
+    # hipErrorNoDevice).  So torch first: its runtime is then the one in the process and the soname resolves to it.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, fp, i32p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)
     cfgp = C.POINTER(CemConfig)

@@ -21,3 +21,13 @@ def test_capi_minimal_example_runs_and_is_deterministic():
     assert s1 == s2 and it1 == it2
     a3, s3, _ = capi_minimal.main(seed=4)
     assert not np.array_equal(a1, a3)
+
+
+def test_build_then_smoke_in_one_fresh_process():
+    """`__graft_entry__.build()` dlopens the library (symbol check) before anything has imported torch; `smoke()` in the same process
+    must still run: the library has to end up on the HIP runtime torch brought, not on a second copy from /opt/rocm (`_capi.load`
+    imports torch first for that reason; without it `cem_planner_create` fails with hipErrorNoDevice)."""
+    import subprocess
+    r = subprocess.run([sys.executable, '-c', 'import __graft_entry__ as g; g.build(); g.smoke(); print("both ok")'], cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'both ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
