@@ -9,16 +9,19 @@ import os
 
 import yaml
 
+# key order as the reference's loader produces it (models.yaml, policies.yaml, agents.yaml, then the experiment file's `options`):
+# pretty_print — what scripts/train.py dumps into params.txt — shows it
 DEFAULTS = {
+    'models': {
+        'mlp_ensemble': dict(ensemble_size=15, batch_size=64, validation_split=0.2, learning_rate=0.00025, learning_rate_schedule=True,
+                             training_steps=5000, mlp_params=dict(n_layers=4, units=128, activation='tf.nn.relu', dropout_rate=0.0)),
+    },
     'policies': {
         'cem_mpc': dict(horizon=8, iterations=10, smoothing=0.0, n_samples=150, n_elite=15, particles=5, stddev_threshold=0.25,
                         noise_stddev=0.001),
         'safe_cem_mpc': dict(horizon=8, iterations=9, smoothing=0.0, n_samples=500, n_elite=20, particles=45, stddev_threshold=0.25,
                              noise_stddev=0.01, posterior_mean_threashold=0.15),
-    },
-    'models': {
-        'mlp_ensemble': dict(ensemble_size=15, batch_size=64, validation_split=0.2, learning_rate=0.00025, learning_rate_schedule=True,
-                             training_steps=5000, mlp_params=dict(n_layers=4, units=128, activation='tf.nn.relu', dropout_rate=0.0)),
+        'random_shooting_mpc': dict(horizon=10, n_samples=1000),      # (config/policies.yaml:21-23; the class itself cannot be constructed)
     },
     'agents': {
         'agent': dict(replay_buffer_size=1000000, action_repeat=6, add_observation_noise=False),
@@ -28,12 +31,13 @@ DEFAULTS = {
 }
 
 
-def _options(log_frequency, eval_steps, eval_len, train_iterations, fps=60, **extra):
+def _options(log_frequency, eval_steps, eval_len, train_iterations, fps=60, seed=None):
     o = dict(trainer_options=dict(video_log_frequency=-1, log_frequency=log_frequency, max_video_length=1000,
                                   eval_interaction_steps=eval_steps, eval_episode_length=eval_len,
-                                  training_logger_params=dict(fps=fps)),
-             train_iterations=train_iterations, agent='mbrl_agent', environment='MbrlSafexp-PointSimpleGoal1-v0')
-    o.update(extra)
+                                  training_logger_params=dict(fps=fps)))
+    if seed is not None:
+        o['seed'] = seed                      # (config/tune_policy.yaml:10: between trainer_options and train_iterations)
+    o.update(train_iterations=train_iterations, agent='mbrl_agent', environment='MbrlSafexp-PointSimpleGoal1-v0')
     return o
 
 

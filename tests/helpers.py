@@ -20,6 +20,47 @@ def make_problem(obs_dim=60, act_dim=2, E=5, n_layers=4, seed=1234, bias_noise=0
     return pb
 
 
+def with_action_bounds(pb, low, high):
+    """The same problem with another action Box (MpcPolicy.sampling_params, mpc_policy.py:45-57): per-dimension (low, high), or a Box
+    with an infinite bound anywhere — `is_bounded()` is then False and EVERY dimension takes the +-100 / 0 / 100 branch.  The
+    normaliser's action columns are the Box when it is bounded and the range the samples then cover (+-100) when it is not — the data
+    range TransitionModel._fit_statistics falls back to (transition_model.py:42-50) — so scaled inputs stay O(1)."""
+    low, high = np.asarray(low, np.float32), np.asarray(high, np.float32)
+    A = pb['low'].shape[0]
+    assert low.shape == (A,) and high.shape == (A,)
+    pb = dict(pb)
+    pb['low'], pb['high'] = low, high
+    O = pb['state'].shape[0]
+    imin, imax = pb['inputs_min'].copy(), pb['inputs_max'].copy()
+    bounded = bool(np.all(np.isfinite(low)) and np.all(np.isfinite(high)))
+    imin[O:] = low if bounded else np.float32(-100.0)
+    imax[O:] = high if bounded else np.float32(100.0)
+    pb['inputs_min'], pb['inputs_max'] = imin, imax
+    return pb
+
+
+def random_action_bounds(rng, A):
+    """(kind, low, high): 'unit' Box(-1, 1), 'asym' per-dimension bounds of mixed sign / width (one dimension may be a single point),
+    'unbounded' (all infinite) or 'mixed' (some infinite: the reference then ignores the finite ones too)."""
+    kind = str(rng.choice(['unit', 'asym', 'asym', 'asym', 'asym', 'unbounded', 'mixed', 'mixed']))
+    if kind == 'unit':
+        return kind, -np.ones(A, np.float32), np.ones(A, np.float32)
+    centre = rng.uniform(-2.0, 2.0, A)
+    half = rng.uniform(0.05, 1.5, A)
+    if kind == 'asym' and A > 1 and rng.random() < 0.25:
+        half[int(rng.integers(0, A))] = 0.0                 # low == high: sigma0 = 0, every sample of that dimension is the bound
+    low, high = (centre - half).astype(np.float32), (centre + half).astype(np.float32)
+    if kind == 'unbounded':
+        low[:], high[:] = -np.inf, np.inf
+    elif kind == 'mixed':
+        j = int(rng.integers(0, A))
+        if rng.random() < 0.5:
+            high[j] = np.inf
+        else:
+            low[j] = -np.inf
+    return kind, low, high
+
+
 def configs(pb, N, H, P, E, k, I=3, variant='cem', thr=-1.0, noise=0.0, post=0.3, smoothing=0.0,
             sampling=True, scale=True, world_size=1, rank=0, chunks_per_tile=0, use_graph=False, rollout_segments=0, select_mode=0, precision='fp32'):
     sp = pb['scorer']

@@ -1,0 +1,218 @@
+"""MpcPolicy.sampling_params (mpc_policy.py:45-57) and the sample / clip of CemMpc.do_generate_action (cem_mpc.py:37-48) on the HIP
+path with action spaces other than Box(-1, 1): per-dimension asymmetric bounds (mu0 = (high + low) / 2, sigma0 = (high - low) / 2
+differ per dimension and from (0, 1)), an unbounded Box (the +-100 / 0 / 100 branch) and a Box with ONE infinite bound
+(`is_bounded()` is False, so every dimension takes that branch and the finite bounds are ignored).  With Box(-1, 1) — what every
+other GPU test uses — `eps * sigma0 + mu0` is the identity and `lb / ub` are the same for every dimension, so an indexing slip in
+cem_init_kernel (`mu0[i % A]`) or in the clip (`lb[a]`) would pass; here it cannot.
+
+Oracle = oracle/cem_oracle.py (PARITY UNPINNED: this repo's restatement of the reference)."""
+import numpy as np
+import pytest
+
+from oracle import cem_oracle as o
+from tests import helpers as hp
+from tests.test_gpu_parity import ATOL, FULL_SIZE_ATOL
+
+pytestmark = pytest.mark.gpu
+INF = np.inf
+
+# name: (obs_dim, low, high).  obs 60 + 3 actions: one input block per wave (the action quad of block 3 holds 3 action features);
+# obs 100 + 12 actions: two input blocks per wave, actions spread over quads 25..27; obs 62 + 2: the actions straddle no quad boundary
+# but sit at the END of block 3; obs 63 + 3: they straddle the block-3 / block-4 boundary (features 63 | 64, 65).
+BOXES = {
+    'asym3': (60, [-0.3, 0.5, -2.0], [1.7, 0.9, 0.25]),
+    'asym2_one_point': (60, [0.25, -1.5], [0.25, 0.5]),                       # low == high in dimension 0: sigma0 = 0 there
+    'asym3_straddle': (63, [-3.0, 0.125, 1.0], [-1.0, 0.375, 5.0]),
+    'asym12': (100, list(np.linspace(-2.0, 0.9, 12)), list(np.linspace(-1.5, 3.0, 12))),
+    'unbounded2': (60, [-INF, -INF], [INF, INF]),
+    'mixed3': (60, [-1.0, -INF, -0.5], [1.0, 2.0, 0.5]),                      # one infinite bound: +-100 for ALL dimensions
+    'mixed12_high': (100, [-1.0] * 12, [1.0] * 11 + [INF]),
+}
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), 'gpu tests need an MI355X'
+    return torch
+
+
+def _problem(name, E=5, seed=71):
+    O, low, high = BOXES[name]
+    A = len(low)
+    pb = hp.make_problem(O, A, E, 4, seed=seed)
+    return hp.with_action_bounds(pb, low, high), O, A
+
+
+def test_boxes_cover_both_branches_and_are_not_the_identity():
+    """The cases above are what they claim to be (host-side check of the test inputs themselves)."""
+    for name, (O, low, high) in BOXES.items():
+        lb, ub, mu0, sg0 = o.sampling_params(np.array(low, np.float32), np.array(high, np.float32))
+        if name.startswith(('unbounded', 'mixed')):
+            assert np.all(lb == -100) and np.all(ub == 100) and np.all(mu0 == 0) and np.all(sg0 == 100), name
+        else:
+            assert len(set(mu0.tolist())) > 1 and len(set(sg0.tolist())) > 1, name     # per-dimension values differ
+            assert not np.any((mu0 == 0) & (sg0 == 1)), name                           # no dimension is the identity map
+            np.testing.assert_array_equal(mu0, (np.float32(high) + np.float32(low)) / np.float32(2))
+            np.testing.assert_array_equal(sg0, (np.float32(high) - np.float32(low)) / np.float32(2))
+
+
+@pytest.mark.parametrize('name', list(BOXES))
+def test_sampling_params_reach_the_device(name):
+    """cem_init_kernel: mu / sigma after plan_begin are sampling_params broadcast to [H, A] (cem_mpc.py:37-40); iteration 0 samples
+    clip(eps * sigma0 + mu0, lb, ub) bit for bit; after one refit iteration 1 samples from the refitted mu / sigma with the same
+    per-dimension clip, bit for bit (cem_mpc.py:44-48)."""
+    torch = _torch()
+    pb, O, A = _problem(name)
+    N, H, P, E, k, I = 96, 7, 5, 5, 9, 2
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I)
+    pl = hp.make_planner(pb, pcfg)
+    ea, em, eo = hp.noise(I, N, H, A, P, O, seed=17)
+    if not name.startswith(('unbounded', 'mixed')):
+        ea = (ea * np.float32(1.3)).astype(np.float32)         # wider draws: a good share of the samples lands on a bound
+    lb, ub, mu0, sg0 = o.sampling_params(pb['low'], pb['high'])
+    pl.plan_begin(pb['state'], eps_act=ea, eps_model=em)
+    torch.cuda.synchronize()
+    ms = pl.mu_sigma().cpu().numpy().copy()
+    np.testing.assert_array_equal(ms[0], np.broadcast_to(mu0, (H, A)))
+    np.testing.assert_array_equal(ms[1], np.broadcast_to(sg0, (H, A)))
+    pl.plan_rollout(0)
+    torch.cuda.synchronize()
+    a0 = pl.actions().cpu().numpy().copy()
+    ref0 = o.sample_actions(np.broadcast_to(mu0, (H, A)), np.broadcast_to(sg0, (H, A)), lb, ub, ea[0])
+    np.testing.assert_array_equal(a0, ref0)
+    assert np.all(a0 >= lb) and np.all(a0 <= ub)
+    if not name.startswith(('unbounded', 'mixed')):
+        for a in range(A):
+            if sg0[a] > 0:          # the clip is live on both sides in every dimension, and most samples are interior
+                assert (a0[..., a] == lb[a]).any() and (a0[..., a] == ub[a]).any() and ((a0[..., a] > lb[a]) & (a0[..., a] < ub[a])).mean() > 0.3, (name, a)
+            else:
+                assert np.all(a0[..., a] == lb[a])
+    scores = pl.scores_local().cpu().numpy().copy()
+    assert np.all(np.isfinite(scores))
+    pl.plan_select(0)
+    torch.cuda.synchronize()
+    ms1 = pl.mu_sigma().cpu().numpy().copy()
+    mu, sigma, best, best_score, elite, stop = o.select_and_refit(scores, a0, ms[0], ms[1], np.zeros(A, np.float32), np.float32(-np.inf), ocfg)
+    np.testing.assert_array_equal(np.sort(pl.elite_idx().cpu().numpy()), np.sort(elite))
+    np.testing.assert_allclose(ms1[0], mu, rtol=1e-5, atol=1e-6 * max(1.0, float(np.abs(ub).max())))
+    np.testing.assert_allclose(ms1[1], sigma, rtol=2e-5, atol=1e-6 * max(1.0, float(np.abs(ub).max())))
+    pl.plan_rollout(1)
+    torch.cuda.synchronize()
+    a1 = pl.actions().cpu().numpy().copy()
+    np.testing.assert_array_equal(a1, o.sample_actions(ms1[0], ms1[1], lb, ub, ea[1]))        # from the GPU's own refit: bit-exact
+    pl.plan_select(1)
+    a, s, n_it = pl.plan_end(eps_out=eo)
+    assert n_it == 2 and np.isfinite(s)
+    pl.close()
+
+
+@pytest.mark.parametrize('variant', ['cem', 'safe'])
+@pytest.mark.parametrize('name', ['asym3', 'asym12', 'asym3_straddle', 'unbounded2', 'mixed3'])
+def test_whole_plan_with_other_boxes_matches_oracle(name, variant):
+    """generate_action end to end on identical noise tensors with a non-trivial action Box: scores per iteration, elite sets,
+    mu / sigma, the returned action within the north-star's 1e-5 relative."""
+    torch = _torch()
+    pb, O, A = _problem(name, seed=73)
+    N, H, P, E, k, I = 160, 8, 5, 5, 16, 4
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, variant=variant, noise=0.01, post=0.3, smoothing=0.1)
+    pl = hp.make_planner(pb, pcfg)
+    ea, em, eo = hp.noise(I, N, H, A, P, O, seed=19)
+    trace = []
+    ra, rs, rit = o.do_generate_action(pb['state'], pb['weights'], pb['inputs_min'], pb['inputs_max'], pb['low'], pb['high'],
+                                       ea, em, eo, ocfg, pb['scorer'], trace=trace)
+    scale = max(1.0, float(np.abs(o.sampling_params(pb['low'], pb['high'])[1]).max()))
+    pl.plan_begin(pb['state'], eps_act=ea, eps_model=em)
+    elites_match = True
+    for it in range(I):
+        pl.plan_rollout(it)
+        torch.cuda.synchronize()
+        scores = pl.scores_local().cpu().numpy().copy()
+        if elites_match:
+            np.testing.assert_allclose(pl.actions().cpu().numpy(), trace[it]['actions'], rtol=1e-5, atol=1e-6 * scale)
+            bad = np.abs(scores - trace[it]['scores']) > FULL_SIZE_ATOL
+            assert bad.mean() < 0.05, '%s iteration %d: %d/%d scores differ' % (name, it, bad.sum(), N)
+        pl.plan_select(it)
+        torch.cuda.synchronize()
+        elite = pl.elite_idx().cpu().numpy()
+        if elites_match and set(elite.tolist()) != set(trace[it]['elite'].tolist()):
+            assert hp.elite_sets_equal_modulo_ties(trace[it]['scores'], elite, trace[it]['elite'], FULL_SIZE_ATOL)
+            elites_match = False
+        if elites_match:
+            ms = pl.mu_sigma().cpu().numpy()
+            np.testing.assert_allclose(ms[0], trace[it]['mu'], rtol=1e-5, atol=1e-6 * scale)
+            np.testing.assert_allclose(ms[1], trace[it]['sigma'], rtol=2e-5, atol=1e-6 * scale)
+    a, s, n_it = pl.plan_end(eps_out=eo)
+    assert n_it == rit == I
+    assert elites_match, 'an elite set differed from the oracle (a near-tie on the k-th score?)'
+    np.testing.assert_allclose(a, ra, rtol=1e-5, atol=1e-7 * scale)
+    assert abs(s - rs) <= FULL_SIZE_ATOL
+    pl.close()
+
+
+@pytest.mark.parametrize('name', ['asym3', 'asym12', 'unbounded2'])
+def test_philox_plan_with_other_boxes(name):
+    """The generator path (no noise tensors: cem_sample_kernel draws eps itself) with a non-trivial Box: the plan equals the same
+    plan on its dumped noise bit for bit, eagerly and as a captured hipGraph, and its iteration-0 actions are the oracle's sample of
+    the dumped eps."""
+    torch = _torch()
+    pb, O, A = _problem(name, seed=75)
+    N, H, P, E, k, I = 128, 6, 5, 5, 13, 3
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, noise=0.02)
+    pl = hp.make_planner(pb, pcfg)
+    fa, fm, fo = pl.fill_noise(seed=9, call=4)
+    a1, s1, i1 = pl.plan(pb['state'], seed=9, call=4)
+    a2, s2, i2 = pl.plan(pb['state'], eps_act=fa, eps_model=fm, eps_out=fo.cpu().numpy())
+    np.testing.assert_array_equal(a1, a2)
+    assert s1 == s2 and i1 == i2 == I
+    lb, ub, mu0, sg0 = o.sampling_params(pb['low'], pb['high'])
+    pl.plan_begin(pb['state'], seed=9, call=4)
+    pl.plan_rollout(0)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(pl.actions().cpu().numpy(),
+                                  o.sample_actions(np.broadcast_to(mu0, (H, A)), np.broadcast_to(sg0, (H, A)), lb, ub, fa[0].cpu().numpy()))
+    pl.plan_select(0)
+    pl.plan_end()
+    _, gcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, noise=0.02, use_graph=True)
+    pg = hp.make_planner(pb, gcfg)
+    for _ in range(3):
+        ag, sg, ig = pg.plan(pb['state'], seed=9, call=4)
+    assert pg.graph_status() == 'graph'
+    np.testing.assert_array_equal(ag, a1)
+    assert sg == s1
+    # the returned action is a sampled first action (+ output noise), so it lies inside the Box widened by a few noise stddevs
+    assert np.all(a1 >= lb - 0.2) and np.all(a1 <= ub + 0.2)
+    pl.close(); pg.close()
+
+
+def test_a_swapped_parameter_would_be_caught(monkeypatch):
+    """The tests above are sensitive to the values they are about: a planner built with mu0 / sigma0 swapped, or with lb / ub taken
+    from the wrong dimension, samples different actions than the oracle (i.e. `test_sampling_params_reach_the_device` would fail)."""
+    torch = _torch()
+    from ethz_safe_learning_amd import planner as planner_mod
+    pb, O, A = _problem('asym3')
+    N, H, P, E, k = 64, 5, 5, 5, 6
+    ea, em, eo = hp.noise(1, N, H, A, P, O, seed=17)
+    ea = (ea * np.float32(1.3)).astype(np.float32)
+    lb, ub, mu0, sg0 = o.sampling_params(pb['low'], pb['high'])
+    ref0 = o.sample_actions(np.broadcast_to(mu0, (H, A)), np.broadcast_to(sg0, (H, A)), lb, ub, ea[0])
+    real = planner_mod.sampling_params
+
+    def first_actions():
+        ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=1)
+        pl = hp.make_planner(pb, pcfg)
+        pl.plan_begin(pb['state'], eps_act=ea, eps_model=em)
+        pl.plan_rollout(0)
+        torch.cuda.synchronize()
+        out = pl.actions().cpu().numpy().copy()
+        pl.plan_select(0); pl.plan_end(); pl.close()
+        return out
+    np.testing.assert_array_equal(first_actions(), ref0)
+    mutations = {
+        'mu0 <-> sigma0': lambda l, h: (lambda r: (r[0], r[1], r[3], r[2]))(real(l, h)),
+        'lb <-> ub rolled by one dimension': lambda l, h: (lambda r: (np.roll(r[0], 1), np.roll(r[1], 1), r[2], r[3]))(real(l, h)),
+        'mu0 rolled by one dimension': lambda l, h: (lambda r: (r[0], r[1], np.roll(r[2], 1), r[3]))(real(l, h)),
+    }
+    for what, fn in mutations.items():
+        monkeypatch.setattr(planner_mod, 'sampling_params', fn)
+        assert not np.array_equal(first_actions(), ref0), what
+    monkeypatch.setattr(planner_mod, 'sampling_params', real)

@@ -35,6 +35,8 @@ def _random_rollout_case(seed):
              scale=bool(rng.random() < 0.8), post=float(rng.choice([0.15, 0.3, 0.5])))
     # (drawn last, so the cases above are the ones of earlier rounds) the split-product rollout where it applies: half of the eligible cases
     c['precision'] = 'bf16x3' if (c['units'] <= 128 and rng.random() < 0.5) else 'fp32'
+    # (round 4, drawn after everything else) the action Box: per-dimension bounds, unbounded, one infinite bound (mpc_policy.py:45-57)
+    c['box'], c['low'], c['high'] = hp.random_action_bounds(rng, A)
     return c
 
 
@@ -42,7 +44,7 @@ def _random_rollout_case(seed):
 def test_random_shape_rollout_scores(seed):
     c = _random_rollout_case(seed)
     O, A, E, P, N, H = c['O'], c['A'], c['E'], c['P'], c['N'], c['H']
-    pb = hp.make_problem(O, A, E, c['L'], seed=200 + seed, units=c['units'])
+    pb = hp.with_action_bounds(hp.make_problem(O, A, E, c['L'], seed=200 + seed, units=c['units']), c['low'], c['high'])
     ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=max(1, N // 10), I=1, variant=c['variant'], post=c['post'],
                             sampling=c['sampling'], scale=c['scale'], chunks_per_tile=c['rc'], rollout_segments=c['seg'],
                             precision=c['precision'])
@@ -125,10 +127,12 @@ def _random_plan_case(seed):
     P = E * int(rng.integers(1, 3))
     N = int(rng.integers(2, 400))
     k = int(rng.choice([1, 2, max(1, N // 10), max(1, N // 2), N]))
-    return dict(O=O, A=A, E=E, P=P, N=N, k=min(k, N), H=int(rng.integers(1, 9)), I=int(rng.integers(2, 5)),
-                variant=str(rng.choice(['cem', 'safe'])), smoothing=float(rng.choice([0.0, 0.1, 0.5])),
-                thr=float(rng.choice([-1.0, -1.0, 0.3, 0.6])), noise=float(rng.choice([0.0, 0.05])),
-                select_mode=int(rng.choice([0, 1, 2, 3])), use_graph=False, units=int(rng.choice([64, 64, 192])))
+    c = dict(O=O, A=A, E=E, P=P, N=N, k=min(k, N), H=int(rng.integers(1, 9)), I=int(rng.integers(2, 5)),
+             variant=str(rng.choice(['cem', 'safe'])), smoothing=float(rng.choice([0.0, 0.1, 0.5])),
+             thr=float(rng.choice([-1.0, -1.0, 0.3, 0.6])), noise=float(rng.choice([0.0, 0.05])),
+             select_mode=int(rng.choice([0, 1, 2, 3])), use_graph=False, units=int(rng.choice([64, 64, 192])))
+    c['box'], c['low'], c['high'] = hp.random_action_bounds(rng, A)          # (round 4, drawn last: earlier rounds' shapes unchanged)
+    return c
 
 
 @pytest.mark.parametrize('seed', range(24 * SCALE))
@@ -139,7 +143,7 @@ def test_random_shape_whole_plan_teacher_forced(seed):
     import torch
     c = _random_plan_case(seed)
     O, A, E, P, N, H, I, k = c['O'], c['A'], c['E'], c['P'], c['N'], c['H'], c['I'], c['k']
-    pb = hp.make_problem(O, A, E, 2, seed=400 + seed, units=c['units'])
+    pb = hp.with_action_bounds(hp.make_problem(O, A, E, 2, seed=400 + seed, units=c['units']), c['low'], c['high'])
     ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, variant=c['variant'], post=0.3, smoothing=c['smoothing'], thr=c['thr'],
                             noise=c['noise'], select_mode=c['select_mode'])
     pl = hp.make_planner(pb, pcfg)
@@ -162,8 +166,9 @@ def test_random_shape_whole_plan_teacher_forced(seed):
         mu, sigma, best, best_score, ref_elite, stop = o.select_and_refit(scores, actions, ms[0], ms[1], best, best_score, ocfg)
         np.testing.assert_array_equal(np.sort(pl.elite_idx().cpu().numpy()), np.sort(ref_elite), err_msg=str((c, it)))
         got = pl.mu_sigma().cpu().numpy().copy()
-        np.testing.assert_allclose(got[0], mu, rtol=1e-5, atol=1e-6, err_msg=str((c, it)))
-        np.testing.assert_allclose(got[1], sigma, rtol=2e-5, atol=1e-6, err_msg=str((c, it)))
+        amag = max(1.0, float(np.abs(ub).max()))             # mu / sigma live on the scale of the Box (+-100 when it is unbounded)
+        np.testing.assert_allclose(got[0], mu, rtol=1e-5, atol=1e-6 * amag, err_msg=str((c, it)))
+        np.testing.assert_allclose(got[1], sigma, rtol=2e-5, atol=1e-6 * amag, err_msg=str((c, it)))
         ms = got                                        # teacher forcing: the next iteration samples from the GPU's own refit
         # the stop rule compares mean(sigma) with the threshold: only decisive margins are asserted
         margin = abs(float(sigma.mean()) - c['thr'])
@@ -194,6 +199,7 @@ def _random_shard_case(seed):
              rc_full=int(rng.integers(0, 5)), rc_shard=int(rng.integers(0, 5)), seg=int(rng.choice([0, 1, 2, 3])),
              units=int(rng.choice([96, 96, 176])))
     c['precision'] = 'bf16x3' if (c['units'] <= 128 and rng.random() < 0.5) else 'fp32'     # (drawn last: earlier rounds' cases unchanged)
+    c['box'], c['low'], c['high'] = hp.random_action_bounds(rng, A)                           # (round 4)
     return c
 
 
@@ -205,7 +211,7 @@ def test_random_shape_shard_and_tile_invariance(seed):
     import torch
     c = _random_shard_case(seed)
     W, E, P, N, O, A, H = c['W'], c['E'], c['P'], c['N'], c['O'], c['A'], c['H']
-    pb = hp.make_problem(O, A, E, 3, seed=500 + seed, units=c['units'])
+    pb = hp.with_action_bounds(hp.make_problem(O, A, E, 3, seed=500 + seed, units=c['units']), c['low'], c['high'])
 
     def run(world, rank, rc, seg):
         _, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=max(1, N // 10), I=1, variant=c['variant'], post=0.3, world_size=world, rank=rank,
