@@ -211,6 +211,92 @@ def comm_ranks_or_none(pl):
         return None
 
 
+def all_ranks_ok(torch, dist, ok, ctl_dev):
+    """True iff `ok` holds on every rank (one MIN all-reduce over the control group); single process: `ok` itself."""
+    if dist is None:
+        return bool(ok)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=ctl_dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return int(flag.item()) == 1
+
+
+class HeadlineGuard:
+    """The extra legs of a multi-rank run (B5, its split-product form) contain collectives.  If a rank dies or faults INSIDE one, the
+    others block in it and nothing in-process can agree about anything any more — so before the extras start, every rank arms a
+    timer: if the extras have not finished within `seconds`, rank 0 prints the line it already has (headline complete, the extras
+    marked as timed out) and every rank leaves with os._exit, so the launcher sees an orderly end instead of its own timeout and the
+    run keeps its headline."""
+
+    def __init__(self, out, rank, seconds):
+        import threading
+        self.out, self.rank = out, rank
+        self.timer = threading.Timer(seconds + (0.0 if rank == 0 else 5.0), self.fire)
+        self.timer.daemon = True
+        self.seconds = seconds
+
+    def fire(self):
+        if self.rank == 0:
+            line = dict(self.out)
+            for key in ('b5', 'b5_split_bf16x3'):
+                line.setdefault(key, {'error': 'did not finish within %d s (a rank blocked in a collective?); headline printed by the guard' % self.seconds})
+            print(json.dumps(line), flush=True)
+        os._exit(0)
+
+    def __enter__(self):
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
+
+
+def config_leg(torch, name, obs, act, K, N, H, dev, steps, warmup):
+    """One more BASELINE config on the same line as the headline (configs[0], [2], [3] of BASELINE.json; [4] is b5_leg): whole plans
+    timed like the headline (graph replay), then the rollout launch by HIP events on the planner's stream.  Labelled extras —
+    `value` stays B2."""
+    from ethz_safe_learning_amd import CemPlanner, PlannerConfig, synthetic
+    I = 5
+    pb = synthetic.problem(obs, act, K)
+    cfg = PlannerConfig(obs_dim=obs, act_dim=act, ensemble_size=K, particles=K, n_samples=N, horizon=H, n_elite=N // 10, iterations=I,
+                        scorer=pb['scorer'], act_low=pb['low'], act_high=pb['high'], stddev_threshold=-1.0, noise_stddev=1e-3, variant='cem',
+                        use_graph=True)
+    pl = CemPlanner(cfg, device=dev)
+    pl.set_weights(pb['weights'])
+    pl.set_normaliser(pb['inputs_min'], pb['inputs_max'])
+    for i in range(warmup):
+        pl.plan(pb['state'], seed=2029, call=i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        a, s, it = pl.plan(pb['state'], seed=2029, call=warmup + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert it == I and np.all(np.isfinite(a))
+    graph = pl.graph_status() == 'graph'
+    pl.set_timing(True)
+    roll_ms, sel_ms, roll_n = 0.0, 0.0, 0
+    for i in range(3):
+        pl.plan(pb['state'], seed=2030, call=i)
+        tm = pl.last_timing()
+        roll_ms += tm['rollout_ms']; sel_ms += tm['select_ms']; roll_n += tm['rollout_launches']
+    pl.set_timing(False)
+    avg_ms = roll_ms / max(roll_n, 1)
+    flops_launch = synthetic.flops_per_row_step(obs, act) * K * N * H
+    out = dict(workload='%s: obs=%d act=%d K=P=E=%d N=%d H=%d I=5 k=N/10 units=128 layers=4, CemMpc objective, early stop off' % (name, obs, act, K, N, H),
+               plans_per_s=steps / dt, ms_per_plan=1e3 * dt / steps, steps=steps, warmup=warmup,
+               candidate_trajectory_steps_per_s=steps / dt * I * N * H,
+               rollout_ms_per_launch=avg_ms, rollout_launches_timed=roll_n, algorithmic_flops_per_launch=flops_launch,
+               rollout_tflops=flops_launch / (avg_ms * 1e-3) / 1e12,
+               frac_of_fp32_mfma_peak=flops_launch / (avg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+               plan_frac_of_fp32_mfma_peak=I * flops_launch / (dt / steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+               select_us_per_iteration=1e3 * sel_ms / max(roll_n, 1),
+               kernel=rollout_kernel_name(pl, obs, act), chunks_per_tile=pl.tiles()[0], tiles=int(len(pl.tiles()[1])),
+               horizon_segments=pl.segments()[0], hip_graph=graph)
+    pl.close()
+    return out
+
+
 def b5_leg(torch, dist, pb, G, rank, dev, native, steps, warmup, rehearse_world=0, ctl_dev=None, precision='fp32'):
     """BASELINE.json configs[4], strong-scaled: N = 65536 candidates (K = P = E = 5, H = 30, I = 5, k = 6554) sharded over the G
     ranks of this run, one all-gather of the scores per CEM iteration.  Timed like the headline: barrier + synchronize on both
@@ -224,10 +310,27 @@ def b5_leg(torch, dist, pb, G, rank, dev, native, steps, warmup, rehearse_world=
     cfg = PlannerConfig(obs_dim=obs, act_dim=act, ensemble_size=K, particles=K, n_samples=N, horizon=H, n_elite=k, iterations=I,
                         scorer=pb['scorer'], act_low=pb['low'], act_high=pb['high'], stddev_threshold=-1.0, noise_stddev=1e-3, variant='cem',
                         world_size=W, rank=0 if rehearse_world else rank, use_graph=not rehearse_world, precision=precision)
-    pl = CemPlanner(cfg, device=dev)
-    pl.set_weights(pb['weights'])
-    pl.set_normaliser(pb['inputs_min'], pb['inputs_max'])
-    n_seen = 0
+    # Everything that can fail on ONE rank only (handle creation, the communicator, its rank count) happens before the leg's first
+    # collective, and the ranks then agree — over the control group — whether all of them got through: a rank that threw here while
+    # the others walked into ncclAllGather / dist.barrier would leave them blocked until the launcher's timeout, headline lost.
+    pl, n_seen, setup_error = None, 0, None
+    try:
+        pl = CemPlanner(cfg, device=dev)
+        pl.set_weights(pb['weights'])
+        pl.set_normaliser(pb['inputs_min'], pb['inputs_max'])
+        if native and not rehearse_world:
+            pl.comm_init()
+            n_seen = comm_ranks_or_none(pl)
+            if n_seen not in (None, G):
+                raise RuntimeError('rank %d: the RCCL communicator has %s ranks, --gpus is %d' % (rank, n_seen, G))
+    except Exception as e:
+        setup_error = str(e)[:300]
+    if not all_ranks_ok(torch, dist, setup_error is None, ctl_dev or dev):
+        if pl is not None:
+            if pl.has_comm:
+                pl.comm_destroy()
+            pl.close()
+        return {'error': 'skipped on every rank: set-up failed on %s' % ('this rank: ' + setup_error if setup_error else 'another rank')}
     if rehearse_world:
         exchange = 'rehearsal: device copy of this rank\'s shard (1 process playing rank 0 of %d)' % W
         pl.scores_global().copy_(torch.from_numpy(np.random.default_rng(0).standard_normal(N).astype(np.float32)))
@@ -242,9 +345,6 @@ def b5_leg(torch, dist, pb, G, rank, dev, native, steps, warmup, rehearse_world=
                 pl.plan_select(it)
             return pl.plan_end()
     elif native:
-        pl.comm_init()
-        n_seen = comm_ranks_or_none(pl)
-        assert n_seen in (None, G), 'rank %d: the RCCL communicator has %s ranks, --gpus is %d' % (rank, n_seen, G)
         exchange = 'ncclAllGather inside the library, on the planner stream'
 
         def one_plan(i):
@@ -303,6 +403,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-split-leg', action='store_true')
+    ap.add_argument('--no-configs', action='store_true', help='skip the B1 / B3 / B4 / B5-rank extras of a single-GPU run')
+    ap.add_argument('--no-b5', action='store_true', help='skip the B5 extras of a multi-GPU run')
+    ap.add_argument('--extras-timeout', type=int, default=240, help='seconds after which a multi-rank run prints its headline without the extras')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--chunks', type=int, default=0)
     ap.add_argument('--segments', type=int, default=0, help='rollout work-queue segments: 0 auto, 1 off')
@@ -459,17 +562,31 @@ def main():
     # BASELINE config 5 (N = 65536 over the node's GPUs) rides along on every multi-GPU run; CEM_BENCH_B5_REHEARSAL=R rehearses one
     # rank of R on a one-GPU box
     rehearse = int(os.environ.get('CEM_BENCH_B5_REHEARSAL', '0'))
-    if G > 1 or rehearse > 0:
+    if (G > 1 or rehearse > 0) and not args.no_b5:
         if native:
             pl.comm_destroy()                          # one communicator at a time
-        out['b5'] = b5_leg(torch, dist, pb, G, rank, dev, native, steps=min(args.steps, 20), warmup=min(max(args.warmup, 2), 5),
-                           rehearse_world=rehearse if G == 1 else 0, ctl_dev=ctl_dev)
-        if not args.no_split_leg:                      # the same sharded plan on the opt-in split-product rollout: a labelled extra, never `value`
-            try:
+        # an extra must never cost the run its headline: failures a rank can have on its own are agreed on before the leg's first
+        # collective (b5_leg), and a leg that blocks is cut off by the guard, which prints the headline as it stands
+        with HeadlineGuard(out, rank, args.extras_timeout):
+            out['b5'] = b5_leg(torch, dist, pb, G, rank, dev, native, steps=min(args.steps, 20), warmup=min(max(args.warmup, 2), 5),
+                               rehearse_world=rehearse if G == 1 else 0, ctl_dev=ctl_dev)
+            if not args.no_split_leg:                  # the same sharded plan on the opt-in split-product rollout: a labelled extra, never `value`
                 out['b5_split_bf16x3'] = b5_leg(torch, dist, pb, G, rank, dev, native, steps=min(args.steps, 20), warmup=min(max(args.warmup, 2), 5),
                                                 rehearse_world=rehearse if G == 1 else 0, ctl_dev=ctl_dev, precision='bf16x3')
-            except Exception as e:                         # an extra must never cost the run its headline line
-                out['b5_split_bf16x3'] = {'error': str(e)[:300]}
+    if G == 1 and not distributed and not args.no_configs:
+        # the other single-GPU BASELINE configs (and one rank of B5's eight) on the driver's line: labelled extras, `value` stays B2
+        pl.close()
+        legs = {}
+        for name, O_, A_, K_, N_, H_, st_, wu_ in (('B1', 60, 2, 5, 500, 25, 60, 15), ('B3', 60, 2, 16, 8192, 30, 8, 3), ('B4', 100, 12, 8, 4096, 50, 10, 3)):
+            try:
+                legs[name] = config_leg(torch, name, O_, A_, K_, N_, H_, dev, steps=st_, warmup=wu_)
+            except Exception as e:
+                legs[name] = {'error': str(e)[:300]}
+        try:
+            legs['B5_rank'] = b5_leg(torch, None, pb, 1, 0, dev, False, steps=10, warmup=3, rehearse_world=8, ctl_dev=ctl_dev)
+        except Exception as e:
+            legs['B5_rank'] = {'error': str(e)[:300]}
+        out['configs'] = legs
     if G == 1 and not distributed and not args.no_split_leg:
         try:
             out['split_bf16x3'] = split_leg(torch, pb, dev, steps=min(args.steps, 50), warmup=min(max(args.warmup, 3), 10), n_per_gpu=args.n_per_gpu)

@@ -5,7 +5,7 @@
 #include "cem_train_tile.h"
 #include "cem_rollout_split.h"
 #include "cem_rollout_wide.h"
-#include "../../include/cem_mpc.h"
+#include "../include/cem_mpc.h"
 
 #include <dlfcn.h>
 

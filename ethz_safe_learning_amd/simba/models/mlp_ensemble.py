@@ -30,7 +30,14 @@ class MlpEnsemble(object):
         self.dropout_rate = float(self.mlp_params.get('dropout_rate', 0.0))       # Dropout after every hidden layer, training_step only (mlp_ensemble.py:15,21,138)
         if not 0.0 <= self.dropout_rate < 1.0:
             raise ValueError('dropout_rate must be in [0, 1)')
-        self._dropout_seed = 0 if seed is None else int(seed)
+        # Keras draws Dropout masks from TensorFlow's global generator; the counterpart here is numpy's (the one the reference's own
+        # split and shuffles use, seeded by scripts/train.py): an unseeded model with dropout takes its mask seed from it, so two runs
+        # only share a mask stream if they share np.random's state.  (No draw when the rate is 0 — the shipped value — so np.random's
+        # stream is untouched there.)  The mask STREAM is parity-unpinned by construction; rate and 1 / (1 - rate) scaling are pinned.
+        if seed is not None:
+            self._dropout_seed = int(seed)
+        else:
+            self._dropout_seed = int(np.random.randint(0, 2 ** 31 - 1)) if self.dropout_rate > 0.0 else 0
         rng = np.random.default_rng(seed)
         self._weights = [self._init_member(rng) for _ in range(ensemble_size)]
         self.version = 0

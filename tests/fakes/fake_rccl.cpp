@@ -90,7 +90,20 @@ int ncclCommInitRank(void **comm, int n, NcclId id, int rank)
     return 0;
 }
 
-int ncclCommCount(void *comm, int *n) { *n = ((Comm *)comm)->n; return 0; }
+// Failure knobs (environment, read per call; every rank of a test sets the same ones):
+//   CEM_FAKE_RCCL_CAPTURE=error       ncclAllGather on a CAPTURING stream returns ncclInvalidUsage and enqueues nothing — an RCCL that
+//                                     refuses to be captured;
+//   CEM_FAKE_RCCL_CAPTURE=invalidate  ... performs an operation that is illegal under capture (hipStreamSynchronize of the capturing
+//                                     stream) and returns success — an RCCL whose call silently invalidates the capture: the caller's
+//                                     later launches and its hipStreamEndCapture fail;
+//   CEM_FAKE_RCCL_COUNT_OFFSET=d      ncclCommCount reports n + d — a communicator that is not the one the launcher asked for.
+// (libfake_rccl_nocount.so is this file built with -DCEM_FAKE_NO_COMMCOUNT: an RCCL without the optional ncclCommCount export.)
+static int env_int(const char *name) { const char *v = std::getenv(name); return v ? std::atoi(v) : 0; }
+static bool env_is(const char *name, const char *val) { const char *v = std::getenv(name); return v && std::strcmp(v, val) == 0; }
+
+#ifndef CEM_FAKE_NO_COMMCOUNT
+int ncclCommCount(void *comm, int *n) { *n = ((Comm *)comm)->n + env_int("CEM_FAKE_RCCL_COUNT_OFFSET"); return 0; }
+#endif
 
 int ncclCommDestroy(void *comm)
 {
@@ -111,6 +124,13 @@ int ncclAllGather(const void *send, void *recv, size_t count, int dtype, void *c
     const size_t bytes = count * 4;
     if (bytes > kSlotBytes) return 4;
     if (c->sh->failed.load()) return 3;                                            // ncclInternalError
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) {
+            if (env_is("CEM_FAKE_RCCL_CAPTURE", "error")) return 5;                // ncclInvalidUsage
+            if (env_is("CEM_FAKE_RCCL_CAPTURE", "invalidate")) { (void)hipStreamSynchronize(stream); (void)hipGetLastError(); return 0; }
+        } else (void)hipGetLastError();
+    }
     // device -> this rank's host slot; barrier (every slot written); all slots -> device; barrier (every rank has copied the slots
     // out before anyone's next gather overwrites one).  Stream operations only, and nothing but pointers in their arguments, so
     // the sequence can be captured into a hipGraph and replayed.

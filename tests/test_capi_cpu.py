@@ -52,7 +52,7 @@ def test_config_struct_matches_header_size(built_lib):
     (dict(particles=3, n_samples=7, n_elite=2, ensemble_size=5), 3),   # tf.split would raise (mlp_ensemble.py:123)
     (dict(n_elite=3000), 1),                             # k > N
     (dict(world_size=3), 1),                             # N % world != 0
-    (dict(horizon=20000), 2),                            # elite list + 2 x H x A floats must fit the select kernel's LDS
+    (dict(horizon=20000, select_mode=1), 2),             # elite list + 2 x H x A floats must fit the ONE-workgroup select kernel's LDS (an explicit request for it)
     (dict(scorer=ScorerConfig(goal_slice=(3, 61), cost_kinds=[(22, 38, 0.2)])), 1),          # goal slice runs past the observation
     (dict(scorer=ScorerConfig(goal_slice=(19, 19), cost_kinds=[(22, 38, 0.2)])), 1),         # empty goal lidar: distance would be +inf
     (dict(scorer=ScorerConfig(goal_slice=(3, 19), cost_kinds=[(38, 22, 0.2)])), 1),          # reversed cost slice

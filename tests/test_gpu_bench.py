@@ -39,6 +39,17 @@ def test_default_bench_line():
     r = _json_line(out.stdout)
     _check(r, 5, 2)
     assert r['config']['hip_graph'] is True
+    # the other BASELINE configs ride along as labelled extras (value stays B2): B1, B3, B4 whole plans + one rank of B5's eight
+    cf = r['configs']
+    assert set(cf) == {'B1', 'B3', 'B4', 'B5_rank'} and not any('error' in v for v in cf.values()), cf
+    rows = {'B1': 5 * 500, 'B3': 16 * 8192, 'B4': 8 * 4096}
+    for name in ('B1', 'B3', 'B4'):
+        c = cf[name]
+        assert c['workload'].startswith(name + ':') and c['hip_graph'] is True and c['tiles'] * c['chunks_per_tile'] * 16 >= rows[name]
+        assert abs(c['plans_per_s'] * c['ms_per_plan'] / 1e3 - 1.0) < 1e-6 and c['kernel'].startswith('void cem_rollout_')
+        assert abs(c['frac_of_fp32_mfma_peak'] - c['algorithmic_flops_per_launch'] / (c['rollout_ms_per_launch'] * 1e-3) / 157.3e12) < 1e-9
+        assert (0.25 if name == 'B1' else 0.5) < c['frac_of_fp32_mfma_peak'] < 1.0 and c['plan_frac_of_fp32_mfma_peak'] < c['frac_of_fp32_mfma_peak']
+    assert cf['B5_rank']['candidates_per_rank'] == 8192 and 0.5 < cf['B5_rank']['rollout_frac_of_fp32_mfma_peak_per_rank'] < 1.0
 
 
 def test_distributed_leg_with_one_rank_over_rccl():

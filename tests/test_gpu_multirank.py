@@ -25,10 +25,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
+FAKE_NOCOUNT = os.path.join(ROOT, 'tests', 'fakes', 'libfake_rccl_nocount.so')
+
+
 @pytest.fixture(scope='module')
 def fake_rccl():
     r = subprocess.run(['make', '-C', os.path.join(ROOT, 'tests', 'fakes')], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    assert r.returncode == 0 and os.path.exists(FAKE), r.stdout
+    assert r.returncode == 0 and os.path.exists(FAKE) and os.path.exists(FAKE_NOCOUNT), r.stdout
     return FAKE
 
 
@@ -53,6 +56,17 @@ CASES = [
 ]
 
 
+# the collective refuses to be captured into a hipGraph (CEM_FAKE_RCCL_CAPTURE=error: ncclAllGather on a capturing stream returns
+# ncclInvalidUsage): cem_planner_plan must drop to eager launches for good (cem_capi.hip: graph_failed), report
+# 'graph-unsupported', and still return the single-rank result bit for bit on every rank, call after call
+CASES += [
+    dict(name='w2_capture_refused', world=2, N=512, H=8, k=51, I=3, variant='cem', seed=87, plan_seed=11, calls=4,
+         env={'CEM_FAKE_RCCL_CAPTURE': 'error'}, expect_status=['eager'] + ['graph-unsupported'] * 3),
+    dict(name='w3_capture_refused_fused_select', world=3, N=24576, H=4, k=2457, I=2, variant='safe', seed=88, plan_seed=12, calls=3,
+         env={'CEM_FAKE_RCCL_CAPTURE': 'error'}, expect_status=['eager'] + ['graph-unsupported'] * 2),
+]
+
+
 @pytest.mark.parametrize('case', CASES, ids=[c['name'] for c in CASES])
 def test_every_rank_of_a_sharded_plan_equals_the_single_rank_plan(case, fake_rccl, tmp_path):
     from tests import helpers as hp
@@ -68,12 +82,16 @@ def test_every_rank_of_a_sharded_plan_equals_the_single_rank_plan(case, fake_rcc
     ref.close()
 
     r = _launch(case['world'], os.path.join(ROOT, 'tests', 'multirank_worker.py'), [str(tmp_path), json.dumps(case)],
-                {'CEM_RCCL_LIBRARY': fake_rccl})
+                dict({'CEM_RCCL_LIBRARY': fake_rccl}, **case.get('env', {})))
     assert r.returncode == 0, r.stdout[-4000:]
+    assert 'cem_mpc: RCCL entry points bound from CEM_RCCL_LIBRARY=' + fake_rccl in r.stdout      # the override is never silent
     for rank in range(case['world']):
         got = np.load(os.path.join(str(tmp_path), 'rank%d.npz' % rank))
         st = json.load(open(os.path.join(str(tmp_path), 'rank%d.json' % rank)))['graph_status']
-        assert st[0] == 'eager' and all(x == 'graph' for x in st[1:]), st      # the collective was captured and replayed
+        if 'expect_status' in case:
+            assert st == case['expect_status'], st
+        else:
+            assert st[0] == 'eager' and all(x == 'graph' for x in st[1:]), st      # the collective was captured and replayed
         for c in range(case['calls']):
             a, s, it, ms, el = expect[c]
             np.testing.assert_array_equal(got['action%d' % c], a, err_msg='rank %d call %d' % (rank, c))
@@ -101,3 +119,30 @@ def test_bench_multi_rank_leg_two_ranks_on_one_gpu(fake_rccl):
     assert d['b5']['exchange'].startswith('ncclAllGather inside the library') and d['b5']['hip_graph'] is True
     sp = d['b5_split_bf16x3']
     assert sp['precision'] == 'bf16x3' and sp['n_ranks'] == 2 and sp['hip_graph'] is True and sp['plans_per_s'] > 0
+
+
+def _bench_two_ranks(env, extra_args=()):
+    r = _launch(2, os.path.join(ROOT, 'bench.py'), ['--gpus', '2', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-b5'] + list(extra_args),
+                dict({'CEM_BENCH_SHARE_GPU': '1'}, **env), timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{') and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-4000:]
+    return json.loads(lines[0]), r.stdout
+
+
+def test_bench_refuses_a_communicator_of_the_wrong_size(fake_rccl):
+    """ncclCommCount disagrees with --gpus (the fake reports n + 1): bench.py must not time a plan over that communicator — every
+    rank sees the mismatch, says so, and ALL ranks fall back together to the host-stepped exchange (no rank is left in a
+    collective the others never enter); the line says which exchange produced the number."""
+    d, log = _bench_two_ranks({'CEM_RCCL_LIBRARY': fake_rccl, 'CEM_FAKE_RCCL_COUNT_OFFSET': '1'})
+    assert 'the RCCL communicator has 3 ranks, --gpus is 2' in log
+    assert d['n_gpus'] == 2 and d['config']['exchange'] == 'torch.distributed all_gather between ctypes calls' and d['config']['hip_graph'] is False
+    assert d['value'] > 0
+
+
+def test_bench_with_an_rccl_that_lacks_ncclCommCount(fake_rccl):
+    """The optional ncclCommCount export is missing (libfake_rccl_nocount.so): cem_planner_comm_ranks returns CEM_ERR_COMM, the library
+    says at load time that the count is unavailable, bench.py reports `not verified` and carries on over the native exchange."""
+    d, log = _bench_two_ranks({'CEM_RCCL_LIBRARY': FAKE_NOCOUNT})
+    assert 'no ncclCommCount: cem_planner_comm_ranks unavailable' in log and 'communicator rank count not verified' in log
+    assert d['n_gpus'] == 2 and d['config']['exchange'].startswith('ncclAllGather inside the library') and d['config']['hip_graph'] is True

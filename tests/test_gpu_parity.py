@@ -259,6 +259,38 @@ def test_select_is_exact_on_given_scores():
     assert s == best_score and it == 1
 
 
+def test_long_horizon_routes_past_the_one_workgroup_select():
+    """2 x H x A floats beyond the one-workgroup select's 140 KB of LDS (H = 9000, A = 2: 144 KB): the automatic select_mode takes the
+    multi-workgroup form instead of refusing the configuration (validate() and the launch path share one routing rule); an explicit
+    select_mode 1 is refused with CEM_ERR_UNSUPPORTED.  Elite set exact, mu / sigma against the oracle on the GPU's own scores."""
+    torch = _torch()
+    from ethz_safe_learning_amd._capi import CemError
+    pb = hp.make_problem(E=1, seed=43)
+    N, H, P, E, k = 24, 9000, 1, 1, 5
+    ocfg, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=1, smoothing=0.25)
+    pl = hp.make_planner(pb, pcfg)
+    pl.plan_begin(pb['state'], seed=3, call=0)
+    pl.plan_rollout(0)
+    torch.cuda.synchronize()
+    actions, scores = pl.actions().cpu().numpy().copy(), pl.scores_local().cpu().numpy().copy()
+    assert np.all(np.isfinite(scores))
+    ms0 = pl.mu_sigma().cpu().numpy().copy()
+    pl.plan_select(0)
+    torch.cuda.synchronize()
+    mu, sigma, best, best_score, ref_elite, stop = o.select_and_refit(scores, actions, ms0[0], ms0[1], np.zeros(2, np.float32), np.float32(-np.inf), ocfg)
+    np.testing.assert_array_equal(np.sort(pl.elite_idx().cpu().numpy()), ref_elite)
+    ms1 = pl.mu_sigma().cpu().numpy()
+    np.testing.assert_allclose(ms1[0], mu, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ms1[1], sigma, rtol=2e-5, atol=1e-6)
+    a, s, it = pl.plan_end(eps_out=np.zeros(2, np.float32))
+    np.testing.assert_array_equal(a, best)
+    pl.close()
+    _, forced = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=1, select_mode=1)
+    with pytest.raises(CemError) as ei:
+        hp.make_planner(pb, forced)
+    assert ei.value.status == 2
+
+
 @pytest.mark.parametrize('mode', [1, 2, 3])
 @pytest.mark.parametrize('case', ['ties', 'all_equal', 'k_equals_n', 'negatives_and_inf', 'large', 'n16000', 'n40000', 'k20000', 'k30000'])
 def test_select_edge_cases(case, mode):
