@@ -446,7 +446,7 @@ int auto_chunks_split(const Dims &d)
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t ctrl, musig, scores_local, scores_global, actions, act_pad, elite, returns, costs, result, wpack, bias_h, bias_mu, bias_var,
+    size_t ctrl, musig, act_bounds, scores_local, scores_global, actions, act_pad, elite, returns, costs, result, wpack, bias_h, bias_mu, bias_var,
         nmin, ndelta, omask, kind_sel, etab, tiles, eps_out, stamps, seg_queue, seg_flags, seg_state,
         ms_hist, ms_sel, ms_counts, ms_best_sc, ms_best_ix, ms_part, ms_colmean, total;
 };
@@ -476,6 +476,7 @@ Layout make_layout(const cem_config_t *c, const Dims &d, size_t max_tiles)
     auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
     l.ctrl = take(sizeof(CtrlBlock));
     l.musig = take((size_t)2 * d.H * d.A * 4);
+    l.act_bounds = take(64 * 4);
     l.scores_local = take((size_t)d.Nloc * 4);
     l.scores_global = d.W > 1 ? take((size_t)d.N * 4) : l.scores_local;
     l.actions = take((size_t)d.N * d.H * d.A * 4);
@@ -772,7 +773,10 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
             et[CEM_ET_SEL0 * CEM_U + f] = ks[f]; et[CEM_ET_SEL1 * CEM_U + f] = ks[CEM_U + f];
         }
     }
-    if (!upload(h->lay.tiles, tiles.data(), tiles.size() * sizeof(Tile6)) || !upload(h->lay.omask, om.data(), om.size() * 4) ||
+    float bounds[64] = {0.f};                              // tf.clip_by_value's lb / ub (cem_mpc.py:48), read by the rollout tiles' sampling prologue
+    for (int a = 0; a < d.A; ++a) { bounds[a] = cfg->act_lb[a]; bounds[32 + a] = cfg->act_ub[a]; }
+    if (!upload(h->lay.act_bounds, bounds, sizeof(bounds)) ||
+        !upload(h->lay.tiles, tiles.data(), tiles.size() * sizeof(Tile6)) || !upload(h->lay.omask, om.data(), om.size() * 4) ||
         !upload(h->lay.kind_sel, ks.data(), ks.size() * 4) || !upload(h->lay.nmin, mn.data(), CEM_U * 4) ||
         !upload(h->lay.ndelta, dl.data(), CEM_U * 4) || !upload(h->lay.etab, h->h_etab.data(), h->h_etab.size() * 4) ||
         hipMemsetAsync(h->ws + h->lay.act_pad, 0, (size_t)d.N * d.H * d.act_nq * 16, h->stream) != hipSuccess ||   // the padding words of the action quads are never written again
@@ -1004,46 +1008,45 @@ int enqueue_begin(cem_planner *h)
     HIPCHK(hipMemcpyAsync(h->ws + l.ctrl, h->h_ctrl, sizeof(CtrlBlock), hipMemcpyHostToDevice, h->stream));
     InitParams ip{}; ip.ctrl = (CtrlBlock *)(h->ws + l.ctrl); ip.musig = (float *)(h->ws + l.musig); ip.HA = d.H * d.A; ip.A = d.A;
     for (int a = 0; a < d.A; ++a) { ip.mu0[a] = h->cfg.act_mu0[a]; ip.sigma0[a] = h->cfg.act_sigma0[a]; }
+    if (h->n_seg > 1) { ip.seg_queue = (uint32_t *)(h->ws + l.seg_queue); ip.seg_flags = (uint32_t *)(h->ws + l.seg_flags); ip.n_ready = (h->n_tiles - h->n_pinned) * (h->n_seg - 1); }
     const int n = std::max(ip.HA, 32);
     hipLaunchKernelGGL(cem_init_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, ip);
     HIPCHK(hipGetLastError());
     return CEM_OK;
 }
 
-int enqueue_rollout(cem_planner *h, int it)
+// One iteration up to the scores: the rollout launch (its tiles sample their own action sequences first: cem_tile_sample_actions), then
+// the particle mean / Beta filter — unless `fold_reduce`: a single-rank whole plan on the CemMpc objective lets the select kernel form
+// the particle mean while it stages its keys (same sum, same order, one launch and one graph node fewer per iteration).
+int enqueue_rollout(cem_planner *h, int it, bool fold_reduce)
 {
     const Dims &d = h->d; const Layout &l = h->lay; char *ws = h->ws;
-    SampleParams sp{}; sp.actions = (float *)(ws + l.actions); sp.musig = (const float *)(ws + l.musig);
-    sp.eps_act = h->eps_act ? h->eps_act + (size_t)it * d.N * d.H * d.A : nullptr;
-    sp.ctrl = (const CtrlBlock *)(ws + l.ctrl); sp.N = d.N; sp.H = d.H; sp.A = d.A; sp.it = it; sp.check_done = 1;
-    sp.act_pad = (float *)(ws + l.act_pad); sp.pad_shift = d.O - 4 * d.act_q0; sp.pad_floats = 4 * d.act_nq;
-    for (int a = 0; a < d.A; ++a) { sp.lb[a] = h->cfg.act_lb[a]; sp.ub[a] = h->cfg.act_ub[a]; }
     const bool queued = h->n_seg > 1 && !h->eps_model;       // explicit eps_model tensors take the general (MODE 1) kernel
-    if (queued) { sp.seg_queue = (uint32_t *)(ws + l.seg_queue); sp.seg_flags = (uint32_t *)(ws + l.seg_flags); sp.n_ready = (h->n_tiles - h->n_pinned) * (h->n_seg - 1); }
-    const int total = d.N * d.H * ((d.A + 3) / 4);
-    hipLaunchKernelGGL(cem_sample_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, h->stream, sp);
-    HIPCHK(hipGetLastError());
-
     RolloutParams rp; fill_rollout_common(h, rp);
     rp.tiles = (const TileDesc *)(ws + l.tiles); rp.s0 = nullptr; rp.actions = (const float *)(ws + l.actions);
     rp.eps_model = h->eps_model ? h->eps_model + (size_t)it * d.H * d.Btot * d.O : nullptr;
     rp.ret = (float *)(ws + l.returns); rp.costs = h->cfg.variant == CEM_VARIANT_SAFE ? (uint8_t *)(ws + l.costs) : nullptr;
     rp.H = d.H; rp.Bloc = d.Bloc; rp.Btot = d.Btot; rp.it = it; rp.variant = h->cfg.variant; rp.check_done = 1;
     rp.stamps = (long long *)(ws + l.stamps);
+    // the sampler's inputs and outputs (cem_mpc.py:44-48)
+    rp.musig = (const float *)(ws + l.musig); rp.eps_act = h->eps_act ? h->eps_act + (size_t)it * d.N * d.H * d.A : nullptr;
+    rp.act_bounds = (const float *)(ws + l.act_bounds); rp.actions_w = (float *)(ws + l.actions); rp.act_pad_w = (float *)(ws + l.act_pad);
+    rp.pad_shift = d.O - 4 * d.act_q0; rp.pad_floats = 4 * d.act_nq; rp.N = d.N; rp.Nloc = d.Nloc; rp.n_off = d.n_off; rp.n_tiles = h->n_tiles;
     size_t e0 = 0;
     if (h->timing) { e0 = h->ev_kind.size() * 2; h->ev_kind.push_back({(int)e0, 0}); hipEventRecord(get_event(h, e0), h->stream); }
     if (d.wide) HIPCHK(launch_rollout_wide(h, rp, h->n_tiles, rp.eps_model ? 1 : 0));
     else if (d.split) HIPCHK(launch_rollout_split(h->rc, d.NFW, rp.eps_model ? 1 : 0, rp, h->n_tiles, h->stream));
     else if (rp.eps_model) HIPCHK(launch_rollout<1>(h->rc, d.NFW, rp, h->n_tiles, h->stream));
     else if (queued) {
-        rp.seg_queue = sp.seg_queue; rp.seg_flags = sp.seg_flags; rp.seg_state = (f4 *)(ws + l.seg_state);
-        rp.seg_len = h->seg_len; rp.n_seg = h->n_seg; rp.n_tiles = h->n_tiles; rp.n_pinned = h->n_pinned;
+        rp.seg_queue = (uint32_t *)(ws + l.seg_queue); rp.seg_flags = (uint32_t *)(ws + l.seg_flags); rp.seg_state = (f4 *)(ws + l.seg_state);
+        rp.seg_len = h->seg_len; rp.n_seg = h->n_seg; rp.n_pinned = h->n_pinned;
         // one workgroup per pinned tile, then one per (floating tile, segment) item
         HIPCHK(launch_rollout_seg(h->rc, d.NFW, rp, h->n_pinned + h->n_seg * (h->n_tiles - h->n_pinned), h->stream));
     } else HIPCHK(launch_rollout<0>(h->rc, d.NFW, rp, h->n_tiles, h->stream));
     if (h->timing) hipEventRecord(get_event(h, e0 + 1), h->stream);
+    if (fold_reduce) return CEM_OK;
 
-    ReduceParams qp{}; qp.ret = rp.ret; qp.costs = rp.costs; qp.scores = (float *)(ws + l.scores_local); qp.ctrl = sp.ctrl;
+    ReduceParams qp{}; qp.ret = rp.ret; qp.costs = rp.costs; qp.scores = (float *)(ws + l.scores_local); qp.ctrl = rp.ctrl;
     qp.Nloc = d.Nloc; qp.P = d.P; qp.H = d.H; qp.variant = h->cfg.variant; qp.check_done = 1;
     qp.alpha = h->alpha; qp.beta = h->beta; qp.thr = h->cfg.posterior_mean_threashold;
     qp.zero = (uint32_t *)(ws + l.ms_hist); qp.zero_n = (3 * CEM_MS_BINS * 4 + 256) / 4; h->sel_zeroed = true;     // for this iteration's multi-workgroup select
@@ -1052,7 +1055,17 @@ int enqueue_rollout(cem_planner *h, int it)
     return CEM_OK;
 }
 
-int enqueue_select(cem_planner *h, int it)
+// whether a whole plan of this handle folds the particle mean into the select kernel: one rank (the scores need no exchange), the
+// CemMpc objective (no per-step Beta counts), and a population the one-workgroup select serves with its keys staged in LDS
+bool folds_reduce(const cem_planner *h)
+{
+    const Dims &d = h->d;
+    if (d.W != 1 || h->comm || h->cfg.variant != CEM_VARIANT_CEM) return false;
+    bool cache = false;
+    return resolve_select_mode(h->cfg.select_mode, d.N, d.k, (long long)d.H * d.A, h->sel_dyn_limit, false, &cache) == 1 && cache;
+}
+
+int enqueue_select(cem_planner *h, int it, bool fold_reduce)
 {
     (void)it;
     const Dims &d = h->d; const Layout &l = h->lay; char *ws = h->ws;
@@ -1061,6 +1074,7 @@ int enqueue_select(cem_planner *h, int it)
     p.N = d.N; p.k = d.k; p.HA = d.H * d.A; p.A = d.A; p.check_done = 1;
     p.smoothing = h->cfg.smoothing; p.one_minus_smoothing = h->cfg.one_minus_smoothing; p.threshold = h->cfg.stddev_threshold;
     p.stamps = (long long *)(ws + l.stamps) + 64;          // past tile 0's rollout stamps; written by -DCEM_STAMPS builds only
+    if (fold_reduce) { p.ret = (const float *)(ws + l.returns); p.P = d.P; p.scores_w = (float *)(ws + l.scores_local); }   // (folds_reduce(): world 1, so local == global)
     size_t lds = (size_t)((d.k + 3) & ~3) * 4 + (size_t)2 * d.H * d.A * 4;
     // Large populations (the replicated select of a many-GPU plan) go through multi-workgroup kernels (cem_mpc.h select_mode):
     // the fused form (one launch, grid barriers) whenever all its ceil(N / 4096) workgroups are resident at once, the eight-launch
@@ -1187,14 +1201,14 @@ int cem_plan_rollout(cem_planner_t *h, int32_t it)
     if (!h) return CEM_ERR_INVALID_ARG;
     if (!h->in_plan) return CEM_ERR_STATE;
     if (it < 0 || it >= h->d.I) return CEM_ERR_INVALID_ARG;
-    return enqueue_rollout(h, it);
+    return enqueue_rollout(h, it, false);      // the stepwise form always leaves the scores in scores_local (the caller may exchange them)
 }
 
 int cem_plan_select(cem_planner_t *h, int32_t it)
 {
     if (!h) return CEM_ERR_INVALID_ARG;
     if (!h->in_plan) return CEM_ERR_STATE;
-    return enqueue_select(h, it);
+    return enqueue_select(h, it, false);
 }
 
 int cem_plan_end(cem_planner_t *h, const float *eps_out_host, float *action_out, float *best_score_out, int32_t *iters_out)
@@ -1226,10 +1240,11 @@ int cem_planner_plan(cem_planner_t *h, const float *state, uint64_t seed, uint64
             // relaxed mode: RCCL may touch the runtime from its proxy thread while this thread captures
             HIPCHK(hipStreamBeginCapture(h->stream, h->comm ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
             int st = enqueue_begin(h);
+            const bool fold = folds_reduce(h);
             for (int it = 0; it < h->d.I && !st; ++it) {
-                st = enqueue_rollout(h, it);
+                st = enqueue_rollout(h, it, fold);
                 if (!st) st = enqueue_exchange(h);
-                if (!st) st = enqueue_select(h, it);
+                if (!st) st = enqueue_select(h, it, fold);
             }
             if (!st) st = enqueue_end(h, false);
             hipError_t ce = hipStreamEndCapture(h->stream, &h->graph);
@@ -1251,10 +1266,11 @@ int cem_planner_plan(cem_planner_t *h, const float *state, uint64_t seed, uint64
         }
     }
     int st = cem_plan_begin(h, state, seed, call, eps_act_dev, eps_model_dev); if (st) return st;
+    const bool fold = folds_reduce(h);                  // the same launches as the captured form
     for (int it = 0; it < h->d.I; ++it) {
-        st = cem_plan_rollout(h, it); if (st) return st;
+        st = enqueue_rollout(h, it, fold); if (st) return st;
         st = enqueue_exchange(h); if (st) return st;
-        st = cem_plan_select(h, it); if (st) return st;
+        st = enqueue_select(h, it, fold); if (st) return st;
     }
     return cem_plan_end(h, eps_out_host, action_out, best_score_out, iters_out);
 }

@@ -97,7 +97,7 @@ __device__ __forceinline__ void cem_wide_kloop(f4 (&acc)[CEM_WIDE_OB], WideRing 
     }
 }
 
-// MODE 0: planning (actions from the padded quad layout the sample kernel writes, Philox noise).  MODE 1: caller-supplied action /
+// MODE 0: planning (actions from the padded quad layout the tile's own prologue writes, cem_tile_sample_actions; Philox noise).  MODE 1: caller-supplied action /
 // noise tensors and the trajectory / head-moment outputs of cem_unfold_sequences.  The epilogue, the scorer terms and the
 // bookkeeping are cem_rollout_tile's (its macros, with RC = 1), on the same per-member feature table; the hidden layers' biases
 // are two table rows per layer here (256 features).
@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256, 2) void cem_rollout_wide_kernel(const WidePara
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RolloutParams &p = wp.r;
     if (p.check_done && p.ctrl->done) return;
+    cem_tile_sample_actions(p, (int)blockIdx.x, 0, p.H, true);
     constexpr int RC = 1, NFW = 2;                         // 16-row tiles; obs + act <= 128: a wave owns input blocks w and w + 4
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
