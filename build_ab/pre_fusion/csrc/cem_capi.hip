@@ -5,7 +5,7 @@
 #include "cem_train_tile.h"
 #include "cem_rollout_split.h"
 #include "cem_rollout_wide.h"
-#include "../../include/cem_mpc.h"
+#include "../include/cem_mpc.h"
 
 #include <dlfcn.h>
 
@@ -307,8 +307,7 @@ static const double kChunkStart[2][4][3] = {{{0.2034, 0.1732, 0.1596}, {0.1580, 
 static const double kChunkNext[2][4] = {{0.1340, 0.1340, 0.1335, 0.1320}, {0.1920, 0.1840, 0.1807, 0.1932}};   // (rc 1: B3 / B5 at one-chunk tiles, 0.130 - 0.136; m = 6 alone gives 0.123)
 #define CEM_MAX_DEVICES 64
 // workgroups of a <rc, nfw> tile one CU keeps resident, from the kernels' VGPR counts (512 registers per SIMD lane; round 3:
-// plain kernel 139/159/186/218, 165/217/253/288; segment kernel 144/163/190/223, 171/221/255/292; round 4, with the sampler as the tiles'
-// prologue: 153/161/189/222, 167/219/243/293 and 157/163/190/223, 172/222/255/294), [form][nfw - 1][rc - 1]
+// plain kernel 139/159/186/218, 165/217/253/288; segment kernel 144/163/190/223, 171/221/255/292), [form][nfw - 1][rc - 1]
 static const int kResidentStatic[2][2][4] = {{{3, 3, 2, 2}, {3, 2, 2, 1}}, {{3, 3, 2, 2}, {2, 2, 2, 1}}};
 
 template <int RC, int NFW>
@@ -447,7 +446,7 @@ int auto_chunks_split(const Dims &d)
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t ctrl, musig, act_bounds, scores_local, scores_global, actions, act_pad, elite, returns, costs, result, wpack, bias_h, bias_mu, bias_var,
+    size_t ctrl, musig, scores_local, scores_global, actions, act_pad, elite, returns, costs, result, wpack, bias_h, bias_mu, bias_var,
         nmin, ndelta, omask, kind_sel, etab, tiles, eps_out, stamps, seg_queue, seg_flags, seg_state,
         ms_hist, ms_sel, ms_counts, ms_best_sc, ms_best_ix, ms_part, ms_colmean, total;
 };
@@ -477,7 +476,6 @@ Layout make_layout(const cem_config_t *c, const Dims &d, size_t max_tiles)
     auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
     l.ctrl = take(sizeof(CtrlBlock));
     l.musig = take((size_t)2 * d.H * d.A * 4);
-    l.act_bounds = take(64 * 4);
     l.scores_local = take((size_t)d.Nloc * 4);
     l.scores_global = d.W > 1 ? take((size_t)d.N * 4) : l.scores_local;
     l.actions = take((size_t)d.N * d.H * d.A * 4);
@@ -579,7 +577,6 @@ struct cem_planner {
     // pinned host staging
     CtrlBlock *h_ctrl;
     float *h_result;
-    const CtrlBlock *d_h_ctrl; float *d_h_result;     // the same two blocks as the DEVICE addresses them (hipHostGetDevicePointer)
     // timing
     bool timing; std::vector<hipEvent_t> ev; float roll_ms, sel_ms; int roll_n;
     std::vector<std::pair<int, int>> ev_kind;   // (event index of start, kind 0 rollout / 1 select)
@@ -731,12 +728,6 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
     if (hipHostMalloc((void **)&h->h_ctrl, sizeof(CtrlBlock), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **)&h->h_result, 64 * 4, hipHostMallocDefault) != hipSuccess) return fail(CEM_ERR_HIP);
     std::memset(h->h_ctrl, 0, sizeof(CtrlBlock));
-    std::memset(h->h_result, 0, 64 * 4);
-    {   // kernels read the staged control block and write the plan's result in place (no copy nodes around a plan)
-        void *dc = nullptr, *dr = nullptr;
-        if (hipHostGetDevicePointer(&dc, h->h_ctrl, 0) != hipSuccess || hipHostGetDevicePointer(&dr, h->h_result, 0) != hipSuccess) return fail(CEM_ERR_HIP);
-        h->d_h_ctrl = (const CtrlBlock *)dc; h->d_h_result = (float *)dr;
-    }
     auto upload = [&](size_t off, const void *src, size_t bytes) {
         return hipMemcpyAsync(h->ws + off, src, bytes, hipMemcpyHostToDevice, h->stream) == hipSuccess;
     };
@@ -781,10 +772,7 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
             et[CEM_ET_SEL0 * CEM_U + f] = ks[f]; et[CEM_ET_SEL1 * CEM_U + f] = ks[CEM_U + f];
         }
     }
-    float bounds[64] = {0.f};                              // tf.clip_by_value's lb / ub (cem_mpc.py:48), read by the rollout tiles' sampling prologue
-    for (int a = 0; a < d.A; ++a) { bounds[a] = cfg->act_lb[a]; bounds[32 + a] = cfg->act_ub[a]; }
-    if (!upload(h->lay.act_bounds, bounds, sizeof(bounds)) ||
-        !upload(h->lay.tiles, tiles.data(), tiles.size() * sizeof(Tile6)) || !upload(h->lay.omask, om.data(), om.size() * 4) ||
+    if (!upload(h->lay.tiles, tiles.data(), tiles.size() * sizeof(Tile6)) || !upload(h->lay.omask, om.data(), om.size() * 4) ||
         !upload(h->lay.kind_sel, ks.data(), ks.size() * 4) || !upload(h->lay.nmin, mn.data(), CEM_U * 4) ||
         !upload(h->lay.ndelta, dl.data(), CEM_U * 4) || !upload(h->lay.etab, h->h_etab.data(), h->h_etab.size() * 4) ||
         hipMemsetAsync(h->ws + h->lay.act_pad, 0, (size_t)d.N * d.H * d.act_nq * 16, h->stream) != hipSuccess ||   // the padding words of the action quads are never written again
@@ -1013,48 +1001,49 @@ hipEvent_t get_event(cem_planner *h, size_t i)
 int enqueue_begin(cem_planner *h)
 {
     const Dims &d = h->d; const Layout &l = h->lay;
+    HIPCHK(hipMemcpyAsync(h->ws + l.ctrl, h->h_ctrl, sizeof(CtrlBlock), hipMemcpyHostToDevice, h->stream));
     InitParams ip{}; ip.ctrl = (CtrlBlock *)(h->ws + l.ctrl); ip.musig = (float *)(h->ws + l.musig); ip.HA = d.H * d.A; ip.A = d.A;
-    ip.host_ctrl = h->d_h_ctrl;                          // the block stage_ctrl filled, read from pinned host memory by the kernel itself
     for (int a = 0; a < d.A; ++a) { ip.mu0[a] = h->cfg.act_mu0[a]; ip.sigma0[a] = h->cfg.act_sigma0[a]; }
-    if (h->n_seg > 1) { ip.seg_queue = (uint32_t *)(h->ws + l.seg_queue); ip.seg_flags = (uint32_t *)(h->ws + l.seg_flags); ip.n_ready = (h->n_tiles - h->n_pinned) * (h->n_seg - 1); }
-    const int n = std::max<int>(ip.HA, (int)(sizeof(CtrlBlock) / 4));
+    const int n = std::max(ip.HA, 32);
     hipLaunchKernelGGL(cem_init_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, ip);
     HIPCHK(hipGetLastError());
     return CEM_OK;
 }
 
-// One iteration up to the scores: the rollout launch (its tiles sample their own action sequences first: cem_tile_sample_actions), then
-// the particle mean / Beta filter — unless `fold_reduce`: a single-rank whole plan on the CemMpc objective lets the select kernel form
-// the particle mean while it stages its keys (same sum, same order, one launch and one graph node fewer per iteration).
-int enqueue_rollout(cem_planner *h, int it, bool fold_reduce)
+int enqueue_rollout(cem_planner *h, int it)
 {
     const Dims &d = h->d; const Layout &l = h->lay; char *ws = h->ws;
+    SampleParams sp{}; sp.actions = (float *)(ws + l.actions); sp.musig = (const float *)(ws + l.musig);
+    sp.eps_act = h->eps_act ? h->eps_act + (size_t)it * d.N * d.H * d.A : nullptr;
+    sp.ctrl = (const CtrlBlock *)(ws + l.ctrl); sp.N = d.N; sp.H = d.H; sp.A = d.A; sp.it = it; sp.check_done = 1;
+    sp.act_pad = (float *)(ws + l.act_pad); sp.pad_shift = d.O - 4 * d.act_q0; sp.pad_floats = 4 * d.act_nq;
+    for (int a = 0; a < d.A; ++a) { sp.lb[a] = h->cfg.act_lb[a]; sp.ub[a] = h->cfg.act_ub[a]; }
     const bool queued = h->n_seg > 1 && !h->eps_model;       // explicit eps_model tensors take the general (MODE 1) kernel
+    if (queued) { sp.seg_queue = (uint32_t *)(ws + l.seg_queue); sp.seg_flags = (uint32_t *)(ws + l.seg_flags); sp.n_ready = (h->n_tiles - h->n_pinned) * (h->n_seg - 1); }
+    const int total = d.N * d.H * ((d.A + 3) / 4);
+    hipLaunchKernelGGL(cem_sample_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, h->stream, sp);
+    HIPCHK(hipGetLastError());
+
     RolloutParams rp; fill_rollout_common(h, rp);
     rp.tiles = (const TileDesc *)(ws + l.tiles); rp.s0 = nullptr; rp.actions = (const float *)(ws + l.actions);
     rp.eps_model = h->eps_model ? h->eps_model + (size_t)it * d.H * d.Btot * d.O : nullptr;
     rp.ret = (float *)(ws + l.returns); rp.costs = h->cfg.variant == CEM_VARIANT_SAFE ? (uint8_t *)(ws + l.costs) : nullptr;
     rp.H = d.H; rp.Bloc = d.Bloc; rp.Btot = d.Btot; rp.it = it; rp.variant = h->cfg.variant; rp.check_done = 1;
     rp.stamps = (long long *)(ws + l.stamps);
-    // the sampler's inputs and outputs (cem_mpc.py:44-48)
-    rp.musig = (const float *)(ws + l.musig); rp.eps_act = h->eps_act ? h->eps_act + (size_t)it * d.N * d.H * d.A : nullptr;
-    rp.act_bounds = (const float *)(ws + l.act_bounds); rp.actions_w = (float *)(ws + l.actions); rp.act_pad_w = (float *)(ws + l.act_pad);
-    rp.pad_shift = d.O - 4 * d.act_q0; rp.pad_floats = 4 * d.act_nq; rp.N = d.N; rp.Nloc = d.Nloc; rp.n_off = d.n_off; rp.n_tiles = h->n_tiles;
     size_t e0 = 0;
     if (h->timing) { e0 = h->ev_kind.size() * 2; h->ev_kind.push_back({(int)e0, 0}); hipEventRecord(get_event(h, e0), h->stream); }
     if (d.wide) HIPCHK(launch_rollout_wide(h, rp, h->n_tiles, rp.eps_model ? 1 : 0));
     else if (d.split) HIPCHK(launch_rollout_split(h->rc, d.NFW, rp.eps_model ? 1 : 0, rp, h->n_tiles, h->stream));
     else if (rp.eps_model) HIPCHK(launch_rollout<1>(h->rc, d.NFW, rp, h->n_tiles, h->stream));
     else if (queued) {
-        rp.seg_queue = (uint32_t *)(ws + l.seg_queue); rp.seg_flags = (uint32_t *)(ws + l.seg_flags); rp.seg_state = (f4 *)(ws + l.seg_state);
-        rp.seg_len = h->seg_len; rp.n_seg = h->n_seg; rp.n_pinned = h->n_pinned;
+        rp.seg_queue = sp.seg_queue; rp.seg_flags = sp.seg_flags; rp.seg_state = (f4 *)(ws + l.seg_state);
+        rp.seg_len = h->seg_len; rp.n_seg = h->n_seg; rp.n_tiles = h->n_tiles; rp.n_pinned = h->n_pinned;
         // one workgroup per pinned tile, then one per (floating tile, segment) item
         HIPCHK(launch_rollout_seg(h->rc, d.NFW, rp, h->n_pinned + h->n_seg * (h->n_tiles - h->n_pinned), h->stream));
     } else HIPCHK(launch_rollout<0>(h->rc, d.NFW, rp, h->n_tiles, h->stream));
     if (h->timing) hipEventRecord(get_event(h, e0 + 1), h->stream);
-    if (fold_reduce) return CEM_OK;
 
-    ReduceParams qp{}; qp.ret = rp.ret; qp.costs = rp.costs; qp.scores = (float *)(ws + l.scores_local); qp.ctrl = rp.ctrl;
+    ReduceParams qp{}; qp.ret = rp.ret; qp.costs = rp.costs; qp.scores = (float *)(ws + l.scores_local); qp.ctrl = sp.ctrl;
     qp.Nloc = d.Nloc; qp.P = d.P; qp.H = d.H; qp.variant = h->cfg.variant; qp.check_done = 1;
     qp.alpha = h->alpha; qp.beta = h->beta; qp.thr = h->cfg.posterior_mean_threashold;
     qp.zero = (uint32_t *)(ws + l.ms_hist); qp.zero_n = (3 * CEM_MS_BINS * 4 + 256) / 4; h->sel_zeroed = true;     // for this iteration's multi-workgroup select
@@ -1063,29 +1052,15 @@ int enqueue_rollout(cem_planner *h, int it, bool fold_reduce)
     return CEM_OK;
 }
 
-// whether a whole plan of this handle folds the particle mean into the select kernel: one rank (the scores need no exchange), the
-// CemMpc objective (no per-step Beta counts), and a population the one-workgroup select serves with its keys staged in LDS
-bool folds_reduce(const cem_planner *h)
-{
-    const Dims &d = h->d;
-    if (d.W != 1 || h->comm || h->cfg.variant != CEM_VARIANT_CEM) return false;
-    bool cache = false;
-    return resolve_select_mode(h->cfg.select_mode, d.N, d.k, (long long)d.H * d.A, h->sel_dyn_limit, false, &cache) == 1 && cache;
-}
-
-// fold_final: the select writes the plan's result itself (whole plans only: eps_out is known before the loop) — returns through
-// *folded whether it did (only the one-workgroup kernel does), so the caller knows whether a final kernel is still needed
-int enqueue_select(cem_planner *h, int it, bool fold_reduce, bool fold_final = false, bool have_eps_out = false, bool *folded = nullptr)
+int enqueue_select(cem_planner *h, int it)
 {
     (void)it;
-    if (folded) *folded = false;
     const Dims &d = h->d; const Layout &l = h->lay; char *ws = h->ws;
     SelectParams p{}; p.scores = (const float *)(ws + l.scores_global); p.actions = (const float *)(ws + l.actions);
     p.musig = (float *)(ws + l.musig); p.ctrl = (CtrlBlock *)(ws + l.ctrl); p.elite_idx = (int32_t *)(ws + l.elite);
     p.N = d.N; p.k = d.k; p.HA = d.H * d.A; p.A = d.A; p.check_done = 1;
     p.smoothing = h->cfg.smoothing; p.one_minus_smoothing = h->cfg.one_minus_smoothing; p.threshold = h->cfg.stddev_threshold;
     p.stamps = (long long *)(ws + l.stamps) + 64;          // past tile 0's rollout stamps; written by -DCEM_STAMPS builds only
-    if (fold_reduce) { p.ret = (const float *)(ws + l.returns); p.P = d.P; p.scores_w = (float *)(ws + l.scores_local); }   // (folds_reduce(): world 1, so local == global)
     size_t lds = (size_t)((d.k + 3) & ~3) * 4 + (size_t)2 * d.H * d.A * 4;
     // Large populations (the replicated select of a many-GPU plan) go through multi-workgroup kernels (cem_mpc.h select_mode):
     // the fused form (one launch, grid barriers) whenever all its ceil(N / 4096) workgroups are resident at once, the eight-launch
@@ -1130,10 +1105,6 @@ int enqueue_select(cem_planner *h, int it, bool fold_reduce, bool fold_final = f
             hipLaunchKernelGGL(cem_msel_final_kernel, dim3(1), dim3(256), 0, h->stream, m);
         }
     } else {
-        if (fold_final) {
-            p.result = h->d_h_result; p.eps_out = have_eps_out ? (const float *)(ws + l.eps_out) : nullptr; p.noise_stddev = h->cfg.noise_stddev;
-            if (folded) *folded = true;
-        }
         if (cache) lds += (size_t)CEM_SEL_KWORDS(d.N) * 4;
         if (cache) hipLaunchKernelGGL(cem_select_kernel<true>, dim3(1), dim3(1024), lds, h->stream, p);
         else hipLaunchKernelGGL(cem_select_kernel<false>, dim3(1), dim3(1024), lds, h->stream, p);
@@ -1158,9 +1129,10 @@ int enqueue_end(cem_planner *h, bool have_eps_out)
 {
     const Dims &d = h->d; const Layout &l = h->lay; char *ws = h->ws;
     FinalParams fp{}; fp.ctrl = (const CtrlBlock *)(ws + l.ctrl); fp.eps_out = have_eps_out ? (const float *)(ws + l.eps_out) : nullptr;
-    fp.result = h->d_h_result; fp.A = d.A; fp.noise_stddev = h->cfg.noise_stddev;       // pinned host memory: no copy node behind the kernel
+    fp.result = (float *)(ws + l.result); fp.A = d.A; fp.noise_stddev = h->cfg.noise_stddev;
     hipLaunchKernelGGL(cem_final_kernel, dim3(1), dim3(64), 0, h->stream, fp);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h->h_result, ws + l.result, 64 * 4, hipMemcpyDeviceToHost, h->stream));
     return CEM_OK;
 }
 
@@ -1215,14 +1187,14 @@ int cem_plan_rollout(cem_planner_t *h, int32_t it)
     if (!h) return CEM_ERR_INVALID_ARG;
     if (!h->in_plan) return CEM_ERR_STATE;
     if (it < 0 || it >= h->d.I) return CEM_ERR_INVALID_ARG;
-    return enqueue_rollout(h, it, false);      // the stepwise form always leaves the scores in scores_local (the caller may exchange them)
+    return enqueue_rollout(h, it);
 }
 
 int cem_plan_select(cem_planner_t *h, int32_t it)
 {
     if (!h) return CEM_ERR_INVALID_ARG;
     if (!h->in_plan) return CEM_ERR_STATE;
-    return enqueue_select(h, it, false);
+    return enqueue_select(h, it);
 }
 
 int cem_plan_end(cem_planner_t *h, const float *eps_out_host, float *action_out, float *best_score_out, int32_t *iters_out)
@@ -1254,14 +1226,12 @@ int cem_planner_plan(cem_planner_t *h, const float *state, uint64_t seed, uint64
             // relaxed mode: RCCL may touch the runtime from its proxy thread while this thread captures
             HIPCHK(hipStreamBeginCapture(h->stream, h->comm ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
             int st = enqueue_begin(h);
-            const bool fold = folds_reduce(h);
-            bool final_folded = false;
             for (int it = 0; it < h->d.I && !st; ++it) {
-                st = enqueue_rollout(h, it, fold);
+                st = enqueue_rollout(h, it);
                 if (!st) st = enqueue_exchange(h);
-                if (!st) st = enqueue_select(h, it, fold, true, false, &final_folded);
+                if (!st) st = enqueue_select(h, it);
             }
-            if (!st && !final_folded) st = enqueue_end(h, false);
+            if (!st) st = enqueue_end(h, false);
             hipError_t ce = hipStreamEndCapture(h->stream, &h->graph);
             if (!st && ce == hipSuccess) ce = hipGraphInstantiate(&h->gexec, h->graph, nullptr, nullptr, 0);
             if (st || ce != hipSuccess) {
@@ -1281,19 +1251,12 @@ int cem_planner_plan(cem_planner_t *h, const float *state, uint64_t seed, uint64
         }
     }
     int st = cem_plan_begin(h, state, seed, call, eps_act_dev, eps_model_dev); if (st) return st;
-    const bool fold = folds_reduce(h);                  // the same launches as the captured form
-    if (eps_out_host) HIPCHK(hipMemcpyAsync(h->ws + h->lay.eps_out, eps_out_host, h->d.A * 4, hipMemcpyHostToDevice, h->stream));
-    bool final_folded = false;
     for (int it = 0; it < h->d.I; ++it) {
-        st = enqueue_rollout(h, it, fold); if (st) { h->in_plan = false; return st; }
-        st = enqueue_exchange(h); if (st) { h->in_plan = false; return st; }
-        st = enqueue_select(h, it, fold, true, eps_out_host != nullptr, &final_folded); if (st) { h->in_plan = false; return st; }
+        st = cem_plan_rollout(h, it); if (st) return st;
+        st = enqueue_exchange(h); if (st) return st;
+        st = cem_plan_select(h, it); if (st) return st;
     }
-    h->in_plan = false;
-    if (!final_folded) { st = enqueue_end(h, eps_out_host != nullptr); if (st) return st; }
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if (h->timing) collect_timing(h);
-    return read_result(h, action_out, best_score_out, iters_out);
+    return cem_plan_end(h, eps_out_host, action_out, best_score_out, iters_out);
 }
 
 int cem_comm_unique_id(void *id_out)

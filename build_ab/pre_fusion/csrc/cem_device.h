@@ -1,8 +1,7 @@
 // cem_device.h — gfx950 (CDNA4) device code of the CEM-MPC planner.
 //
-// Kernels (one CEM iteration = rollout [-> reduce] -> select; the sampler is the rollout tiles' prologue, the particle mean of the
-// CemMpc objective is folded into the select's key staging on a single-rank whole plan):
-//   cem_tile_sample_actions  cem_mpc.py:44-48   clip(eps*sigma+mu, lb, ub) -> actions[N][H][A], per tile, inside the rollout launch
+// Kernels (one CEM iteration = sample -> rollout -> reduce -> select):
+//   cem_sample_kernel   cem_mpc.py:44-48        clip(eps*sigma+mu, lb, ub) -> actions[N][H][A]
 //   cem_rollout_kernel  cem_mpc.py:49-55        tile x P, unfold_sequences (transition_model.py:64-77) through
 //                                               the ensemble MLP (mlp_ensemble.py:59-61,122-132,189-193) and
 //                                               the reward/cost scorer (safety_gym.py:110-192) with the done
@@ -110,17 +109,8 @@ struct RolloutParams {
     int32_t it;
     int32_t variant, sampling, check_done;
     ScorerDev sc;
-    // the sampler, folded into the rollout launch (cem_tile_sample_actions; null musig: the caller supplied `actions`, cem_unfold_sequences)
-    const float *musig;          // [2][H][A] this iteration's mu, sigma (cem_mpc.py:39-40,64-65)
-    const float *eps_act;        // this iteration's [N][H][A] standard normals, or null -> Philox
-    const float *act_bounds;     // [2][32] lb, ub of tf.clip_by_value (cem_mpc.py:48)
-    float *actions_w;            // = actions, written here
-    float *act_pad_w;            // = act_pad as floats: action a of (n, t) at [(n*H + t)*pad_floats + pad_shift + a]
-    int32_t pad_shift, pad_floats;
-    int32_t N, Nloc, n_off;      // all candidates; this rank's shard [n_off, n_off + Nloc)
     // horizon-segment work queue (cem_rollout_seg_kernel): items (segment, tile) in segment-major order
-    uint32_t *seg_queue;         // [3] ticket counter, FIFO tail, finished floating tiles; zero between launches (the launch's last floating
-                                 // workgroup resets it; cem_init_kernel clears it at the start of every plan)
+    uint32_t *seg_queue;         // [2] ticket counter, FIFO tail; zeroed by the sample kernel of the same iteration
     uint32_t *seg_flags;         // [n_float * (n_seg - 1)] FIFO of ready floating items ((tile << 8 | segment) + 1; 0 = not written yet)
     f4 *seg_state;               // [n_float][2*NFW*RC*256 + 64] state a floating tile carries across a segment boundary
     int32_t seg_len, n_seg, n_tiles, n_pinned;
@@ -425,61 +415,6 @@ __device__ __forceinline__ void cem_scorer_terms(const f4 sn, const float D, con
     pm0 = fminf(fminf(pm0, fmaxf(lid[2], sel0[2])), fmaxf(lid[3], sel0[3]));
     pm1 = fminf(fminf(pm1, fmaxf(lid[0], sel1[0])), fmaxf(lid[1], sel1[1]));
     pm1 = fminf(fminf(pm1, fmaxf(lid[2], sel1[2])), fmaxf(lid[3], sel1[3]));
-}
-
-// cem_mpc.py:44-48 inside the rollout launch: a = clip(eps * sigma + mu, lb, ub) (tf.random.normal(mean, stddev) = eps * stddev + mean as
-// a separate multiply and add; tf.clip_by_value), eps keyed on the GLOBAL (candidate, step, iteration) or read from the caller's tensor.
-// A workgroup samples what ITS tile is about to read — its own candidates, steps [t0, t1) — into both layouts (`actions` [N][H][A] for
-// the select kernel and the explicit-tensor rollout forms, the padded quads for the hot kernel) and reads it back after one barrier:
-// no workgroup ever consumes another's samples inside the launch, so nothing has to be coherent across CUs or XCDs.  The P tiles
-// that share a candidate (one per particle) each draw the same values from the same counters and store the same words — a few
-// hundred VALU instructions per tile and horizon, next to 30 steps of ~10 K cycles each.  On a candidate-sharded rank (world > 1) the
-// select still runs over ALL N candidates, so the tiles also share out the sequences of the OTHER ranks' candidates (`actions` only):
-// tile b of n_tiles takes the b-th slice of those (N - Nloc) * H * ceil(A / 4) draws.  With this the sampler costs no launch of its own
-// (it was 4.8 us + a graph-node gap per iteration at B2).  The caller waits (vmcnt(0)) and barriers before the first action load.
-__device__ __forceinline__ void cem_sample_store(const RolloutParams &p, const int n, const int t, const int z, const PhiloxKey key, const bool pad)
-{
-    const int A = p.A, HA = p.H * A;
-    f4 e;
-    if (p.eps_act) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int a = 4 * z + r; e[r] = p.eps_act[((size_t)n * p.H + t) * A + (a < A ? a : A - 1)]; }
-    } else e = cem_normal4((uint32_t)n, (uint32_t)t, (uint32_t)p.it, (uint32_t)z, CEM_STREAM_ACT, key);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int a = 4 * z + r;
-        if (a < A) {
-            float v = e[r] * p.musig[HA + t * A + a] + p.musig[t * A + a];             // tf.random.normal(mean, stddev)
-            v = fminf(fmaxf(v, p.act_bounds[a]), p.act_bounds[32 + a]);                // tf.clip_by_value
-            p.actions_w[((size_t)n * p.H + t) * A + a] = v;
-            if (pad) p.act_pad_w[((size_t)n * p.H + t) * p.pad_floats + p.pad_shift + a] = v;   // padding words stay 0 (zeroed at create)
-        }
-    }
-}
-
-__device__ __forceinline__ void cem_tile_sample_actions(const RolloutParams &p, const int tile_idx, const int t0, const int t1, const bool foreign)
-{
-    if (!p.musig) return;                                    // wave-uniform (a kernel argument)
-    const TileDesc td = p.tiles[tile_idx];
-    const int AZ = (p.A + 3) >> 2, nst = t1 - t0;
-    const PhiloxKey key = cem_key(p.ctrl);
-    const int own = td.cnt * nst * AZ;
-    for (int idx = (int)threadIdx.x; idx < own; idx += 256) {
-        const int z = idx % AZ, tt = (idx / AZ) % nst, r_ = idx / (AZ * nst);
-        cem_sample_store(p, td.act_base + r_, t0 + tt, z, key, true);
-    }
-    if (foreign && p.Nloc < p.N) {                           // the other ranks' candidates, shared out over this rank's tiles
-        const long long total = (long long)(p.N - p.Nloc) * p.H * AZ;
-        const long long per = (total + p.n_tiles - 1) / p.n_tiles;
-        const long long lo = per * tile_idx, hi = (lo + per < total) ? lo + per : total;
-        for (long long idx = lo + (long long)threadIdx.x; idx < hi; idx += 256) {
-            const int z = (int)(idx % AZ), t = (int)((idx / AZ) % p.H);
-            const int jn = (int)(idx / ((long long)AZ * p.H));
-            cem_sample_store(p, jn < p.n_off ? jn : jn + p.Nloc, t, z, key, false);
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): this wave's stores are acknowledged (a barrier alone does not drain them)
-    __syncthreads();
 }
 
 // One tile for steps [t_begin, t_end) of the horizon.  SEG false: the whole horizon (t_begin = 0, t_end = H).  SEG true: one
@@ -871,7 +806,6 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (p.check_done && p.ctrl->done) return;
-    cem_tile_sample_actions(p, (int)blockIdx.x, 0, p.H, true);
     cem_rollout_tile<RC, NFW, MODE, false>(p, smem, (int)blockIdx.x, 0, p.H);
 }
 
@@ -896,7 +830,6 @@ __global__ __launch_bounds__(256) void cem_rollout_seg_kernel(const RolloutParam
     __shared__ uint32_t item_s;
     if (p.check_done && p.ctrl->done) return;
     if ((int)blockIdx.x < p.n_pinned) {
-        cem_tile_sample_actions(p, (int)blockIdx.x, 0, p.H, true);
         cem_rollout_tile<RC, NFW, 0, true>(p, smem, (int)blockIdx.x, 0, p.H);
         return;
     }
@@ -923,21 +856,7 @@ __global__ __launch_bounds__(256) void cem_rollout_seg_kernel(const RolloutParam
     if (item == 0xffffffffu) return;
     const int tile = (int)(item >> 8), seg = (int)(item & 255u);
     const int t0 = seg * p.seg_len, t1 = (t0 + p.seg_len < p.H) ? t0 + p.seg_len : p.H;
-    // every segment samples the steps IT reads (the epilogue of step t fetches the action of step t + 1): a floating tile's segments
-    // run on different CUs, and nothing sampled by one workgroup is read by another
-    cem_tile_sample_actions(p, tile, t0, t1 < p.H ? t1 + 1 : p.H, seg == 0);
     cem_rollout_tile<RC, NFW, 0, true>(p, smem, tile, t0, t1);
-    if (t1 == p.H) {
-        // the launch's last floating tile leaves the work queue as the next launch needs it (all items have run by then: every ticket
-        // is drawn, every FIFO entry written and read), so no other kernel has to reset it between iterations
-        if (threadIdx.x == 0) item_s = atomicAdd(p.seg_queue + 2, 1u);
-        __syncthreads();
-        if (item_s == n_float - 1u) {
-            const int n_ready = (int)n_float * (p.n_seg - 1);
-            for (int i = (int)threadIdx.x; i < n_ready; i += 256) __hip_atomic_store(p.seg_flags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (threadIdx.x < 3) __hip_atomic_store(p.seg_queue + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
     if (t1 < p.H) {
         // EVERY wave waits for the acknowledgements of its own sc1 state stores (vmcnt(0); the encoding leaves expcnt / lgkmcnt
         // alone) before the barrier: s_barrier does not drain stores on gfx940+, and a workgroup-scope release fence compiles
@@ -954,23 +873,49 @@ __global__ __launch_bounds__(256) void cem_rollout_seg_kernel(const RolloutParam
 // ---------------------------------------------------------------------------------------------------------
 // small kernels of the optimiser loop
 // ---------------------------------------------------------------------------------------------------------
-struct InitParams { CtrlBlock *ctrl; const CtrlBlock *host_ctrl; float *musig; int32_t HA, A; float mu0[32], sigma0[32]; uint32_t *seg_queue, *seg_flags; int32_t n_ready; };
+struct InitParams { CtrlBlock *ctrl; float *musig; int32_t HA, A; float mu0[32], sigma0[32]; };
 
 __global__ void cem_init_kernel(const InitParams p)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    // the plan's control block (Philox key, observation, cleared best-so-far / flags) as the host staged it in PINNED memory: read
-    // from there directly — a copy node of its own in front of every plan cost a 3.6 us blit kernel plus its gap
-    if (p.host_ctrl && i < (int)(sizeof(CtrlBlock) / 4)) reinterpret_cast<uint32_t *>(p.ctrl)[i] = reinterpret_cast<const uint32_t *>(p.host_ctrl)[i];
-    // the rollout launches' work queue starts every plan empty (a launch resets it itself; this covers a plan that ended in a fault)
-    if (p.seg_queue) {
-        if (i < 3) p.seg_queue[i] = 0u;
-        for (int e = i; e < p.n_ready; e += gridDim.x * blockDim.x) p.seg_flags[e] = 0u;
-    }
     if (i < p.HA) { p.musig[i] = p.mu0[i % p.A]; p.musig[p.HA + i] = p.sigma0[i % p.A]; }   // cem_mpc.py:39-40
-    if (!p.host_ctrl) {                                       // (staged by the host along with the rest of the block otherwise: stage_ctrl)
-        if (i < 32) p.ctrl->best[i] = 0.f;                                                     // cem_mpc.py:41
-        if (i == 0) { p.ctrl->best_score = -__builtin_inff(); p.ctrl->done = 0; p.ctrl->iters = 0; p.ctrl->fault = 0; }
+    if (i < 32) p.ctrl->best[i] = 0.f;                                                         // cem_mpc.py:41
+    if (i == 0) { p.ctrl->best_score = -__builtin_inff(); p.ctrl->done = 0; p.ctrl->iters = 0; p.ctrl->fault = 0; }
+}
+
+struct SampleParams {
+    float *actions; const float *musig; const float *eps_act; const CtrlBlock *ctrl;
+    float *act_pad; int32_t pad_shift, pad_floats;          // RolloutParams::act_pad as floats: action a of (n, t) at [(n*H + t)*pad_floats + pad_shift + a]
+    int32_t N, H, A, it, check_done;
+    float lb[32], ub[32];
+    uint32_t *seg_queue, *seg_flags; int32_t n_ready;      // work queue of this iteration's rollout launch, reset here (or null)
+};
+
+__global__ __launch_bounds__(256) void cem_sample_kernel(const SampleParams p)
+{
+    if (p.check_done && p.ctrl->done) return;
+    if (p.seg_queue && blockIdx.x == 0) {
+        if (threadIdx.x < 2) p.seg_queue[threadIdx.x] = 0u;
+        for (int i = threadIdx.x; i < p.n_ready; i += blockDim.x) p.seg_flags[i] = 0u;
+    }
+    const int AZ = (p.A + 3) >> 2;
+    const int total = p.N * p.H * AZ;
+    const int HA = p.H * p.A;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int z = idx % AZ, t = (idx / AZ) % p.H, n = idx / (AZ * p.H);
+        f4 e = (f4){0.f, 0.f, 0.f, 0.f};
+        if (!p.eps_act) e = cem_normal4((uint32_t)n, (uint32_t)t, (uint32_t)p.it, (uint32_t)z, CEM_STREAM_ACT, cem_key(p.ctrl));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = 4 * z + r;
+            if (a < p.A) {
+                const float eps = p.eps_act ? p.eps_act[((size_t)n * p.H + t) * p.A + a] : e[r];
+                float v = eps * p.musig[HA + t * p.A + a] + p.musig[t * p.A + a];          // tf.random.normal(mean, stddev)
+                v = fminf(fmaxf(v, p.lb[a]), p.ub[a]);                                      // tf.clip_by_value
+                p.actions[((size_t)n * p.H + t) * p.A + a] = v;
+                if (p.act_pad) p.act_pad[((size_t)n * p.H + t) * p.pad_floats + p.pad_shift + a] = v;   // padding words stay 0 (zeroed at create)
+            }
+        }
     }
 }
 
@@ -1142,21 +1087,8 @@ __global__ __launch_bounds__(256) void cem_scorer_kernel(const ScorerOpParams p)
     if (j == 0) { p.out[row] = r; if (p.flag) p.flag[row] = ga ? 1 : 0; }
 }
 
-__device__ __forceinline__ float cem_out_noise(const CtrlBlock *ctrl, const float *eps_out, const int a)
-{
-    if (eps_out) return eps_out[a];
-    const f4 e = cem_normal4((uint32_t)(a >> 2), 0u, 0u, 0u, CEM_STREAM_OUT, cem_key(ctrl));
-    return e[a & 3];
-}
-
-
 struct SelectParams {
     const float *scores; const float *actions; float *musig; CtrlBlock *ctrl; int32_t *elite_idx;
-    // the particle mean of the CemMpc objective folded into the key staging (single-rank whole plans; null: read `scores`):
-    // score[i] = (sum over q = 0..P-1, in that order, of ret[q * N + i]) / P  (mpc_policy.py:38-39), also stored to scores_w[i]
-    const float *ret; float *scores_w; int32_t P;
-    // the plan's result written by the select itself (whole plans on this kernel: no final kernel; see FinalParams): null = not here
-    float *result; const float *eps_out; float noise_stddev;
     int32_t N, k, HA, A, check_done;
     float smoothing, one_minus_smoothing, threshold;   // one_minus_smoothing = fl32(1.0 - smoothing) rounded once, as cem_mpc.py:64-65 does
     long long *stamps;           // [8] section stamps of -DCEM_STAMPS diagnostic builds
@@ -1254,32 +1186,8 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
     if (CACHE) {
         for (int i0 = 0; i0 < N; i0 += 4096) {
             float v[4];
-            if (p.ret) {
-                // cem_reduce_kernel's sum for this thread's four candidates: particles in ascending order, eight (clamped, hence
-                // unconditional) loads per candidate in flight; reduce_mean = sum / P
-                float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int q0 = 0; q0 < p.P; q0 += 8) {
-                    float r[8][4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (i0 + j * 1024 < N) {                              // (block-uniform: a slice of 1024 candidates that exists)
-                            const int i = i0 + j * 1024 + tid, ic = i < N ? i : N - 1;
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) r[u][j] = p.ret[(size_t)(q0 + u < p.P ? q0 + u : p.P - 1) * N + ic];
-                        }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (q0 + u < p.P) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) if (i0 + j * 1024 < N) acc[j] = acc[j] + r[u][j];
-                        }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { const int i = i0 + j * 1024 + tid; v[j] = acc[j] / (float)p.P; if (i < N) p.scores_w[i] = v[j]; }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { const int i = i0 + j * 1024 + tid; if (i < N) v[j] = p.scores[i]; }
-            }
+            for (int j = 0; j < 4; ++j) { const int i = i0 + j * 1024 + tid; if (i < N) v[j] = p.scores[i]; }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int i = i0 + j * 1024 + tid;
@@ -1509,15 +1417,8 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
         float ssum = 0.f;
         for (int i = 0; i < HA; ++i) ssum = ssum + newsig[i];
         const float mean_sigma = ssum / (float)HA;
-        const int iters = p.ctrl->iters + 1;
-        const bool stop = mean_sigma <= p.threshold;                                          // cem_mpc.py:66-67
-        p.ctrl->iters = iters;
-        if (stop) p.ctrl->done = 1;
-        if (p.result) {             // (every iteration leaves the result as it stands: the last select that RUNS is the plan's last word)
-            reinterpret_cast<int32_t *>(p.result)[33] = iters;
-            reinterpret_cast<int32_t *>(p.result)[34] = stop ? 1 : p.ctrl->done;
-            reinterpret_cast<int32_t *>(p.result)[35] = p.ctrl->fault;
-        }
+        p.ctrl->iters = p.ctrl->iters + 1;
+        if (mean_sigma <= p.threshold) p.ctrl->done = 1;                                      // cem_mpc.py:66-67
         CEM_SEL_STAMP(6);
     }
     if (tid == 64) {
@@ -1526,23 +1427,11 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
             const float os = bsc[i]; const int op = bpos[i];
             if (op != 0x7fffffff && (bp == 0x7fffffff || os > bs || (os == bs && op < bp))) { bs = os; bp = op; }
         }
-        const bool better = bs > p.ctrl->best_score;                         // strict (cem_mpc.py:58)
-        const int idx = elite[bp];
-        for (int a0 = 0; a0 < p.A; a0 += 4) {
-            f4 e = (f4){0.f, 0.f, 0.f, 0.f};                                                    // the output noise of these four actions: one draw
-            if (p.result && !p.eps_out) e = cem_normal4((uint32_t)(a0 >> 2), 0u, 0u, 0u, CEM_STREAM_OUT, cem_key(p.ctrl));
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int a = a0 + r;
-                if (a < p.A) {
-                    const float b = better ? p.actions[(size_t)idx * HA + a] : p.ctrl->best[a];     // first step's action
-                    if (better) p.ctrl->best[a] = b;
-                    if (p.result) p.result[a] = b + (p.eps_out ? p.eps_out[a] : e[r]) * p.noise_stddev;   // cem_mpc.py:68
-                }
-            }
+        if (bs > p.ctrl->best_score) {                                       // strict (cem_mpc.py:58)
+            const int idx = elite[bp];
+            for (int a = 0; a < p.A; ++a) p.ctrl->best[a] = p.actions[(size_t)idx * HA + a];   // first step's action
+            p.ctrl->best_score = bs;
         }
-        if (better) p.ctrl->best_score = bs;
-        if (p.result) p.result[32] = better ? bs : p.ctrl->best_score;
     }
 }
 
@@ -1994,15 +1883,17 @@ __global__ __launch_bounds__(1024) void cem_msel_fused_kernel(const MSelParams p
 #undef CEM_LDC
 #undef CEM_STC
 
-// What a plan returns (cem_mpc.py:68: best_so_far + N(0, noise_stddev), and best_so_far_score), written where the HOST reads it:
-// `result` is pinned host memory (no device -> host copy node after the plan).  Layout: [0, A) action, [32] score, [33] iterations run,
-// [34] early-stop flag, [35] fault bits.
 struct FinalParams { const CtrlBlock *ctrl; const float *eps_out; float *result; int32_t A; float noise_stddev; };
 
 __global__ void cem_final_kernel(const FinalParams p)
 {
     const int a = threadIdx.x;
-    if (a < p.A) p.result[a] = p.ctrl->best[a] + cem_out_noise(p.ctrl, p.eps_out, a) * p.noise_stddev;   // cem_mpc.py:68
+    if (a < p.A) {
+        float eps;
+        if (p.eps_out) eps = p.eps_out[a];
+        else { const f4 e = cem_normal4((uint32_t)(a >> 2), 0u, 0u, 0u, CEM_STREAM_OUT, cem_key(p.ctrl)); eps = e[a & 3]; }
+        p.result[a] = p.ctrl->best[a] + eps * p.noise_stddev;                                 // cem_mpc.py:68
+    }
     if (a == 0) {
         p.result[32] = p.ctrl->best_score;
         reinterpret_cast<int32_t *>(p.result)[33] = p.ctrl->iters;

@@ -9,11 +9,11 @@ ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out/prof"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats --output-format csv -- python3 "$ROOT/bench.py" --steps 40 --warmup 5 --no-cpu-baseline --no-split-leg > "$OUT/stats.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats --output-format csv -- python3 "$ROOT/bench.py" --steps 40 --warmup 5 --no-cpu-baseline --no-split-leg --no-configs > "$OUT/stats.log" 2>&1
 echo "stats pass done"
 for pass in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE"; do
   tag=$(echo "$pass" | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $pass -d "$OUT/pmc_$tag" -o pmc --output-format csv -- python3 "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-split-leg --no-graph > "$OUT/pmc_$tag.log" 2>&1
+  rocprofv3 --kernel-trace --pmc $pass -d "$OUT/pmc_$tag" -o pmc --output-format csv -- python3 "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-split-leg --no-configs --no-graph > "$OUT/pmc_$tag.log" 2>&1
   echo "pmc pass $tag done"
 done
 python3 "$ROOT/scripts/summarise_profiles.py" "$OUT"

@@ -519,6 +519,37 @@ def test_plan_philox_equals_plan_on_dumped_noise_and_graph():
     assert not np.array_equal(a4, a3)
 
 
+@pytest.mark.parametrize('variant,N,H,k,graph', [('cem', 256, 8, 25, False), ('safe', 256, 8, 25, False), ('cem', 2000, 30, 200, True), ('cem', 2000, 30, 200, False),
+                                                 ('safe', 2000, 30, 80, True), ('cem', 500, 25, 50, True)])
+def test_whole_plan_equals_stepwise_plan(variant, N, H, k, graph):
+    """cem_planner_plan launches rollout -> select per iteration on a single-rank CemMpc plan (the particle mean is formed by the
+    select kernel while it stages its keys); the stepwise calls (cem_plan_rollout / cem_plan_select, what a host-stepped multi-rank
+    driver and these tests use) launch rollout -> reduce -> select.  Same sums in the same order: action, best score, mu / sigma, the
+    elite set, the scores and the sampled actions of the last iteration must agree bit for bit — eagerly and as a captured graph, at
+    B2's size too (pinned tiles + floating horizon segments, every segment sampling its own steps)."""
+    torch = _torch()
+    pb = hp.make_problem(seed=62)
+    P = E = 5
+    I = 4
+    _, cfg_w = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, variant=variant, noise=0.03, post=0.3, smoothing=0.1, use_graph=graph)
+    _, cfg_s = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, variant=variant, noise=0.03, post=0.3, smoothing=0.1)
+    pw, ps = hp.make_planner(pb, cfg_w), hp.make_planner(pb, cfg_s)
+    for call in range(3 if graph else 1):
+        aw, sw, iw = pw.plan(pb['state'], seed=21, call=call)
+        ps.plan_begin(pb['state'], seed=21, call=call)
+        for it in range(I):
+            ps.plan_rollout(it)
+            ps.plan_select(it)
+        a2, s2, i2 = ps.plan_end()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(aw, a2)
+        assert sw == s2 and iw == i2 == I
+        for view in ('mu_sigma', 'elite_idx', 'scores_local', 'actions', 'returns'):
+            assert torch.equal(getattr(pw, view)(), getattr(ps, view)()), (view, call)
+    assert pw.graph_status() == ('graph' if graph else 'eager')
+    pw.close(); ps.close()
+
+
 def test_early_stop_and_call_counter():
     torch = _torch()
     pb = hp.make_problem(seed=71)

@@ -40,7 +40,7 @@ def isa():
 def _kernel_bodies(isa, pattern):
     """{mangled name: [instruction lines]} of the kernels whose name matches."""
     out = {}
-    for m in re.finditer(r'^(_Z\w+):.*?\n(.*?)^\s*s_endpgm', isa, re.M | re.S):
+    for m in re.finditer(r'^(_Z\w+):.*?\n(.*?)^\.Lfunc_end', isa, re.M | re.S):       # (to the end of the function: a kernel may hold early s_endpgm's)
         if re.search(pattern, m.group(1)):
             out[m.group(1)] = [l.split(';')[0].strip() for l in m.group(2).splitlines() if l.strip() and not l.lstrip().startswith((';', '.'))]
     return out
