@@ -309,13 +309,13 @@ static const double kChunkNext[2][4] = {{0.1340, 0.1340, 0.1335, 0.1320}, {0.192
 // workgroups of a <rc, nfw> tile one CU keeps resident, from the kernels' VGPR counts (512 registers per SIMD lane; round 3:
 // plain kernel 139/159/186/218, 165/217/253/288; segment kernel 144/163/190/223, 171/221/255/292; round 4, with the sampler as the tiles'
 // prologue: 153/161/189/222, 167/219/243/293 and 157/163/190/223, 172/222/255/294), [form][nfw - 1][rc - 1]
-static const int kResidentStatic[2][2][4] = {{{3, 3, 2, 2}, {3, 2, 2, 1}}, {{3, 3, 2, 2}, {2, 2, 2, 1}}};
+static const int kResidentStatic[2][2][4] = {{{4, 3, 2, 2}, {3, 2, 2, 1}}, {{3, 3, 2, 2}, {3, 2, 2, 1}}};
 
 template <int RC, int NFW>
 int query_resident(bool seg)
 {
     int n = 0;
-    const size_t lds = (size_t)2 * RC * CEM_NG * 1024 + CEM_PART_FLOATS * 4;
+    const size_t lds = CEM_ROLLOUT_LDS_BYTES(RC);
     const hipError_t e = seg ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cem_rollout_seg_kernel<RC, NFW>, 256, lds)
                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cem_rollout_kernel<RC, NFW, 0>, 256, lds);
     if (e != hipSuccess || n < 1) { (void)hipGetLastError(); return 0; }
@@ -927,7 +927,7 @@ namespace {
 template <int RC, int NFW, int MODE>
 hipError_t launch_rollout_t(const RolloutParams &p, int n_tiles, hipStream_t st)
 {
-    const size_t lds = (size_t)2 * RC * CEM_NG * 1024 + CEM_PART_FLOATS * 4;
+    const size_t lds = CEM_ROLLOUT_LDS_BYTES(RC);
     hipLaunchKernelGGL((cem_rollout_kernel<RC, NFW, MODE>), dim3(n_tiles), dim3(256), lds, st, p);
     return hipGetLastError();
 }
@@ -935,7 +935,7 @@ hipError_t launch_rollout_t(const RolloutParams &p, int n_tiles, hipStream_t st)
 template <int RC, int NFW>
 hipError_t launch_rollout_seg_t(const RolloutParams &p, int grid, hipStream_t st)
 {
-    const size_t lds = (size_t)2 * RC * CEM_NG * 1024 + CEM_PART_FLOATS * 4;
+    const size_t lds = CEM_ROLLOUT_LDS_BYTES(RC);
     hipLaunchKernelGGL((cem_rollout_seg_kernel<RC, NFW>), dim3(grid), dim3(256), lds, st, p);
     return hipGetLastError();
 }

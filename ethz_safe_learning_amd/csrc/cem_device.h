@@ -46,6 +46,10 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define CEM_NG 8             // 16-feature blocks in U
 #define CEM_NKIND 5          // goal + up to 4 cost kinds
 #define CEM_PART_FLOATS (CEM_NKIND * 4 * 64)
+// dynamic LDS of the tuned rollout kernels: two activation-exchange buffers, the scorer-term scratch, and the member's CEM_ET_ROWS
+// per-feature table rows (4 KB) the epilogue reads every step
+#define CEM_TAB_LDS_BYTES (CEM_ET_ROWS * CEM_U * 4)
+#define CEM_ROLLOUT_LDS_BYTES(RC_) ((size_t)2 * (RC_) * CEM_NG * 1024 + CEM_PART_FLOATS * 4 + CEM_TAB_LDS_BYTES)
 
 struct TileDesc {
     int32_t row_base;        // local row index of slot 0 (index into returns/costs/traj)
@@ -457,6 +461,13 @@ __device__ __forceinline__ void cem_sample_store(const RolloutParams &p, const i
     }
 }
 
+__device__ __forceinline__ void cem_tile_sample_join()
+{
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): this wave's stores are acknowledged (a barrier alone does not drain them)
+    __syncthreads();
+}
+// WAIT false: the stores are only issued; the caller joins (cem_tile_sample_join) once the rest of its tile set-up is issued too
+template <bool WAIT = true>
 __device__ __forceinline__ void cem_tile_sample_actions(const RolloutParams &p, const int tile_idx, const int t0, const int t1, const bool foreign)
 {
     if (!p.musig) return;                                    // wave-uniform (a kernel argument)
@@ -478,8 +489,7 @@ __device__ __forceinline__ void cem_tile_sample_actions(const RolloutParams &p, 
             cem_sample_store(p, jn < p.n_off ? jn : jn + p.Nloc, t, z, key, false);
         }
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): this wave's stores are acknowledged (a barrier alone does not drain them)
-    __syncthreads();
+    if (WAIT) cem_tile_sample_join();
 }
 
 // One tile for steps [t_begin, t_end) of the horizon.  SEG false: the whole horizon (t_begin = 0, t_end = H).  SEG true: one
@@ -524,6 +534,22 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
         const_cast<float *>(p.etab + (size_t)member_u * (CEM_ET_ROWS + p.L) * CEM_U), 0, (CEM_ET_ROWS + p.L) * CEM_U * 4, 0x00020000);
     const int tab_v = 64 * w + 16 * q;                   // + 256 i
     const int bias_v = 128 * w + 16 * q;                 // the wave's output blocks 2w (and 2w+1: + 64) of a hidden layer
+    // The eight per-feature rows the epilogue needs every step (CEM_ET_NMIN .. CEM_ET_SEL1) are copied into LDS once per tile, one
+    // 16-byte piece per thread, and read from there at the point of use (ds_read_b128, every 16 lanes the same address: a broadcast).
+    // Fetched from memory they had to be requested a whole MFMA stage ahead and held in 32 registers across it — which was the
+    // peak of the kernel's register use (RC 1: 153 -> 129 VGPRs, RC 2 / two input blocks: 219 -> 195).  The hidden layers' biases
+    // (rows CEM_ET_ROWS + l) stay buffer loads a stage ahead: two registers' worth each.
+    const char *tabl = smem + 2 * XB + CEM_PART_FLOATS * 4;
+    {
+        const int ht = (int)threadIdx.x;                 // (hardware thread id: any one-to-one assignment of the 256 pieces)
+        *reinterpret_cast<f4 *>(const_cast<char *>(tabl) + ht * 16) = cem_ld_tab(et_rs, (ht & 31) * 16, (ht >> 5) * 512);
+    }
+#define CEM_TAB(ROW_, TV_) (*reinterpret_cast<const f4 *>(tabl + (ROW_) * 512 + (TV_)))
+#define CEM_SEL0_ROW(TV_) CEM_TAB(CEM_ET_SEL0, TV_)       /* (what CEM_RARE_KINDS_AND_STORE reads; the other kernels that use that macro fetch it from memory) */
+    // one barrier publishes the table rows AND (with the sampler in this launch: the kernel entry issued its stores without waiting)
+    // the tile's own action samples; a resumed segment without a sampler has stage barriers in front of its first table read
+    if (p.musig) cem_tile_sample_join();
+    else if (!resumed) __syncthreads();
 
     // ---- state registers: wave w owns input feature blocks Fo = w + 4 i --------------------------------
     f4 s[NFW][RC];
@@ -618,7 +644,7 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
         if (p.sc.goal_mode) {                                 /* squeeze(relu(goal_dist)), safety_gym.py:172-174 */ \
             _Pragma("unroll") for (int c = 0; c < RC; ++c) pm[0][c] = __builtin_inff(); \
             _Pragma("unroll") for (int i = 0; i < NFW; ++i) { \
-                const f4 selg = cem_ld_tab(et_rs, tab_v + 256 * i, CEM_ET_SEL0 * 512); \
+                const f4 selg = CEM_SEL0_ROW(tab_v + 256 * i); \
                 _Pragma("unroll") for (int c = 0; c < RC; ++c) \
                     _Pragma("unroll") for (int r = 0; r < 4; ++r) pm[0][c] = fminf(pm[0][c], fmaxf(fmaxf(s[i][c][r], 0.f), selg[r])); } } \
         _Pragma("unroll") for (int c = 0; c < RC; ++c) CEM_PAIR_MIN_STORE(0, pm[0][c], pm[1][c], true, c); \
@@ -663,9 +689,9 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
 #pragma unroll
         for (int i = 0; i < NFW; ++i) {
             const int tv = tab_v + 256 * i;
-            const f4 mn4 = cem_ld_tab(et_rs, tv, CEM_ET_NMIN * 512), rd4 = cem_ld_tab(et_rs, tv, CEM_ET_RDELTA * 512);
-            const f4 isact4 = cem_ld_tab(et_rs, tv, CEM_ET_ACT * 512);
-            const f4 sel0 = cem_ld_tab(et_rs, tv, CEM_ET_SEL0 * 512), sel1 = cem_ld_tab(et_rs, tv, CEM_ET_SEL1 * 512);
+            const f4 mn4 = CEM_TAB(CEM_ET_NMIN, tv), rd4 = CEM_TAB(CEM_ET_RDELTA, tv);
+            const f4 isact4 = CEM_TAB(CEM_ET_ACT, tv);
+            const f4 sel0 = CEM_TAB(CEM_ET_SEL0, tv), sel1 = CEM_TAB(CEM_ET_SEL1, tv);
 #pragma unroll
             for (int c = 0; c < RC; ++c) {
                 f4 act4; CEM_LOAD_ACT(act4, i, c, 0);
@@ -768,15 +794,29 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
         for (int i = 0; i < NFW; ++i) {
             const int Fo = w + 4 * i;                  // < 4*NFW: every such block is an input block (zero padded)
             const int tv = tab_v + 256 * i;
-            // everything the epilogue needs from memory is requested BEFORE the MFMA stage
-            const f4 mn4 = cem_ld_tab(et_rs, tv, CEM_ET_NMIN * 512), rd4 = cem_ld_tab(et_rs, tv, CEM_ET_RDELTA * 512);
-            const f4 bm = cem_ld_tab(et_rs, tv, CEM_ET_BMU * 512), bv = cem_ld_tab(et_rs, tv, CEM_ET_BVAR * 512);
-            const f4 om4 = cem_ld_tab(et_rs, tv, CEM_ET_OBS * 512), isact4 = cem_ld_tab(et_rs, tv, CEM_ET_ACT * 512);
-            const f4 sel0 = cem_ld_tab(et_rs, tv, CEM_ET_SEL0 * 512), sel1 = cem_ld_tab(et_rs, tv, CEM_ET_SEL1 * 512);
+            // from memory only the next step's action is requested BEFORE the MFMA stage; the table rows come out of LDS at the point
+            // of use, and the step's model noise is drawn AFTER the stage's MFMAs are issued: Philox and Box-Muller do not depend on
+            // them, so they fill the matrix pipe's drain instead of standing in front of it
             f4 act4[RC], eps4[RC];
 #pragma unroll
+            for (int c = 0; c < RC; ++c) CEM_LOAD_ACT(act4[c], i, c, tn);
+            f4 accm[RC], accv[RC];
+            {
+                const f4 bm = CEM_TAB(CEM_ET_BMU, tv), bv = CEM_TAB(CEM_ET_BVAR, tv);
+#pragma unroll
+                for (int c = 0; c < RC; ++c) { accm[c] = bm; accv[c] = bv; }
+            }
+            CEM_STAMP(2);
+            // the first heads stage also performs the exchange of the last hidden layer's output
+            if (Fo < p.KB_obs) {                                                           // wave-uniform
+                if (i == 0) cem_mfma_stage<RC, CEM_NG, 2, false, CEM_X_EXCHANGE, LA>(accm, accv, hB, wq, smem, xw ^ XB, lane, w);
+                else cem_mfma_stage<RC, CEM_NG, 2, false, CEM_X_REREAD, LA>(accm, accv, hB, wq, smem, xw ^ XB, lane, w);
+            } else if (i == 0) {
+                __syncthreads();                      // keep the barrier count of waves without observation features
+            }
+            CEM_STAMP(3);
+#pragma unroll
             for (int c = 0; c < RC; ++c) {
-                CEM_LOAD_ACT(act4[c], i, c, tn);
                 if (MODE == 1 && p.eps_model) {
                     const int f0 = 16 * Fo + 4 * q;
 #pragma unroll
@@ -790,18 +830,9 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
                                           (uint32_t)(4 * Fo + q), CEM_STREAM_MODEL, key, rscale);
                 }
             }
-            f4 accm[RC], accv[RC];
-#pragma unroll
-            for (int c = 0; c < RC; ++c) { accm[c] = bm; accv[c] = bv; }
-            CEM_STAMP(2);
-            // the first heads stage also performs the exchange of the last hidden layer's output
-            if (Fo < p.KB_obs) {                                                           // wave-uniform
-                if (i == 0) cem_mfma_stage<RC, CEM_NG, 2, false, CEM_X_EXCHANGE, LA>(accm, accv, hB, wq, smem, xw ^ XB, lane, w);
-                else cem_mfma_stage<RC, CEM_NG, 2, false, CEM_X_REREAD, LA>(accm, accv, hB, wq, smem, xw ^ XB, lane, w);
-            } else if (i == 0) {
-                __syncthreads();                      // keep the barrier count of waves without observation features
-            }
-            CEM_STAMP(3);
+            const f4 mn4 = CEM_TAB(CEM_ET_NMIN, tv), rd4 = CEM_TAB(CEM_ET_RDELTA, tv);
+            const f4 om4 = CEM_TAB(CEM_ET_OBS, tv), isact4 = CEM_TAB(CEM_ET_ACT, tv);
+            const f4 sel0 = CEM_TAB(CEM_ET_SEL0, tv), sel1 = CEM_TAB(CEM_ET_SEL1, tv);
 
 #pragma unroll
             for (int c = 0; c < RC; ++c) {
@@ -863,6 +894,9 @@ __device__ __forceinline__ void cem_rollout_tile(const RolloutParams &p, char *s
 #endif
 }
 #undef CEM_LOAD_ACT
+#undef CEM_TAB
+#undef CEM_SEL0_ROW
+#define CEM_SEL0_ROW(TV_) cem_ld_tab(et_rs, (TV_), CEM_ET_SEL0 * 512)
 // CEM_BOOKKEEP, CEM_PART_MIN4, CEM_PAIR_MIN_STORE and CEM_RARE_KINDS_AND_STORE stay defined: cem_rollout_wide.h uses them with the
 // same local names (RC = 1) and undefines them.
 
@@ -871,7 +905,7 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (p.check_done && p.ctrl->done) return;
-    cem_tile_sample_actions(p, (int)blockIdx.x, 0, p.H, true);
+    cem_tile_sample_actions<false>(p, (int)blockIdx.x, 0, p.H, true);
     cem_rollout_tile<RC, NFW, MODE, false>(p, smem, (int)blockIdx.x, 0, p.H);
 }
 
@@ -896,7 +930,7 @@ __global__ __launch_bounds__(256) void cem_rollout_seg_kernel(const RolloutParam
     __shared__ uint32_t item_s;
     if (p.check_done && p.ctrl->done) return;
     if ((int)blockIdx.x < p.n_pinned) {
-        cem_tile_sample_actions(p, (int)blockIdx.x, 0, p.H, true);
+        cem_tile_sample_actions<false>(p, (int)blockIdx.x, 0, p.H, true);
         cem_rollout_tile<RC, NFW, 0, true>(p, smem, (int)blockIdx.x, 0, p.H);
         return;
     }
@@ -925,7 +959,7 @@ __global__ __launch_bounds__(256) void cem_rollout_seg_kernel(const RolloutParam
     const int t0 = seg * p.seg_len, t1 = (t0 + p.seg_len < p.H) ? t0 + p.seg_len : p.H;
     // every segment samples the steps IT reads (the epilogue of step t fetches the action of step t + 1): a floating tile's segments
     // run on different CUs, and nothing sampled by one workgroup is read by another
-    cem_tile_sample_actions(p, tile, t0, t1 < p.H ? t1 + 1 : p.H, seg == 0);
+    cem_tile_sample_actions<false>(p, tile, t0, t1 < p.H ? t1 + 1 : p.H, seg == 0);
     cem_rollout_tile<RC, NFW, 0, true>(p, smem, tile, t0, t1);
     if (t1 == p.H) {
         // the launch's last floating tile leaves the work queue as the next launch needs it (all items have run by then: every ticket
