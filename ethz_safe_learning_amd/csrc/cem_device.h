@@ -320,7 +320,19 @@ struct WRing {
 // is 8 RC MFMAs = 256 RC cycles.  One-chunk tiles of the obs+act <= 64 family read all six blocks right after the barrier
 // (LA 6: B1 -2.6 %, B2 unchanged; 151 VGPRs, still three workgroups per CU); every other form reads one group ahead — more would
 // cost the RC = 2 kernels and the one-chunk obs+act > 64 kernel their third resident workgroup (measured: -3 % at the B5 rank).
-#define CEM_LDS_AHEAD_OF(RC_, NFW_) (((RC_) == 1 && (NFW_) == 1) ? 6 : 1)
+#ifndef CEM_LA_RC1_NFW2
+#define CEM_LA_RC1_NFW2 1
+#endif
+#ifndef CEM_LA_RC2
+#define CEM_LA_RC2 1
+#endif
+#ifndef CEM_LA_RC3
+#define CEM_LA_RC3 1
+#endif
+#ifndef CEM_LA_RC4
+#define CEM_LA_RC4 1
+#endif
+#define CEM_LDS_AHEAD_OF(RC_, NFW_) ((RC_) == 1 ? ((NFW_) == 1 ? 6 : CEM_LA_RC1_NFW2) : ((RC_) == 2 ? CEM_LA_RC2 : ((RC_) == 3 ? CEM_LA_RC3 : CEM_LA_RC4)))
 #define CEM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // One dense stage for this wave: acc{0,1}[c] += W^T-groups . hB.  hB[0..NOWN-1] (the wave's own blocks) are already
