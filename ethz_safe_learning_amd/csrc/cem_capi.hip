@@ -302,9 +302,9 @@ void build_plan_tiles(const Dims &d, int rc, std::vector<Tile6> &out)
 // retires (fitted to m = 6 and to the BASELINE-config sweeps: B3 32, B5 10, B4 8 chunks per CU).  Co-resident tiles now advance
 // together and retire together, so ONE tile more than the residency runs its whole horizon alone: it costs a round of two.
 // Larger tiles re-use each streamed weight group for more rows; smaller ones pack the CUs more evenly and co-reside more easily.
-static const double kChunkStart[2][4][3] = {{{0.2034, 0.1732, 0.1596}, {0.1580, 0.1389, 0.1353}, {0.1489, 0.1342, 0.1342}, {0.1462, 0.1331, 0.1331}},
-                                            {{0.2383, 0.2026, 0.1909}, {0.2110, 0.1848, 0.1848}, {0.2000, 0.1824, 0.1824}, {0.2057, 0.2057, 0.2057}}};
-static const double kChunkNext[2][4] = {{0.1340, 0.1340, 0.1335, 0.1320}, {0.1920, 0.1840, 0.1807, 0.1932}};   // (rc 1: B3 / B5 at one-chunk tiles, 0.130 - 0.136; m = 6 alone gives 0.123)
+// The constants are GENERATED from a sweep by fixed rules (scripts/sweep_chunk_costs.py --emit-table): regenerate them for another device
+// or after a kernel change; tests/test_gpu_tileplan.py bounds how far the resulting automatic choice may be from the best forced one.
+#include "cem_tile_costs.inc"
 #define CEM_MAX_DEVICES 64
 // workgroups of a <rc, nfw> tile one CU keeps resident, from the kernels' VGPR counts (512 registers per SIMD lane; round 3:
 // plain kernel 139/159/186/218, 165/217/253/288; segment kernel 144/163/190/223, 171/221/255/292; round 4, with the sampler as the tiles'
@@ -369,15 +369,19 @@ int num_cus() { return device_facts().cus; }
 // partner and a floater's 30-step chain plus its hand-overs is as long as two whole tiles) and none when the remainder nearly
 // fills the CUs anyway (750 tiles: 0.498 -> 0.492).  Hence: at least two pinned tiles per CU, and a predicted gain of > 4 %.
 static const int kSegMaxSegments = 6, kSegMinSteps = 5;
-static const double kFloatFactor = 0.945;   // pinned + floating launch vs (mean tiles per CU) x the all-resident chunk cost (B2, round 3: 0.3677 ms vs 2.44 x 0.1596)
+// kFloatFactor (cem_tile_costs.inc): pinned + floating launch vs (mean tiles per CU) x the all-resident chunk cost, measured at B2
 
-// cost of `per_cu` tiles of rc chunks queued on one CU that keeps `occ` resident
-double cu_cost(int nfw, int rc, long per_cu, int occ)
+// cost of `per_cu` tiles of rc chunks queued on the BUSIEST CU, which keeps `occ` resident; `fill` = mean tiles per CU / per_cu <= 1.
+// Co-resident tiles are priced by a sweep in which EVERY CU carries them; when only some do (fill < 1), the chip as a whole streams
+// fewer weight groups through L2 and the doubly / triply loaded CUs finish earlier than that sweep says (375 one-chunk tiles: 0.305 ms
+// against 2 x kChunkStart[0][0][1] = 0.335): kPartialFill, measured by the same sweep at 1.5 tiles per CU, scales that back.
+double cu_cost(int nfw, int rc, long per_cu, int occ, double fill)
 {
-    const long k = std::min<long>(per_cu, std::min(occ, 3));
+    const long k = std::min<long>(per_cu, occ);                             // tiles that start together (the table has three columns: a fourth co-resident tile is priced like the third)
     if (k < 1) return 0.0;
     const long later = per_cu - k + (per_cu == k + 1 && k > 1 ? 1 : 0);    // one tile beyond the residency: as dear as two (see above)
-    return (double)rc * ((double)k * kChunkStart[nfw - 1][rc - 1][k - 1] + (double)later * kChunkNext[nfw - 1][rc - 1]);
+    const double relief = k >= 2 ? 1.0 - kPartialFill * (1.0 - std::min(std::max(fill, 0.0), 1.0)) : 1.0;
+    return (double)rc * ((double)k * kChunkStart[nfw - 1][rc - 1][std::min<long>(k, 3) - 1] * relief + (double)later * kChunkNext[nfw - 1][rc - 1]);
 }
 
 int segments_for(const Dims &d, int rc, size_t n_tiles, int requested)
@@ -392,7 +396,7 @@ int segments_for(const Dims &d, int rc, size_t n_tiles, int requested)
     if (S < 2) return 1;
     const double L = (double)n_tiles / kNumCUs;
     const long per_cu = (long)std::ceil(L);
-    const double plain = cu_cost(d.NFW, rc, per_cu, occ), floating = (double)rc * L * kChunkStart[d.NFW - 1][rc - 1][std::min<long>(per_cu, 3) - 1] * kFloatFactor;
+    const double plain = cu_cost(d.NFW, rc, per_cu, occ, L / (double)per_cu), floating = (double)rc * L * kChunkStart[d.NFW - 1][rc - 1][std::min<long>(per_cu, 3) - 1] * kFloatFactor;
     return plain / floating > 1.10 ? S : 1;      // (a remainder that nearly fills the CUs gains nothing: 750 tiles measured 0.498 -> 0.492 ms in round 2)
 }
 
@@ -407,7 +411,7 @@ double tile_plan_cost(const Dims &d, int rc, size_t n_tiles, int requested_segme
             return (double)rc * L * kChunkStart[d.NFW - 1][rc - 1][0] * 1.35;       // (B2 at rc 2: 0.53 ms for 1.23 x 2 chunks per CU, round 3)
         return (double)rc * L * kChunkStart[d.NFW - 1][rc - 1][std::min<long>(per_cu, 3) - 1] * kFloatFactor;
     }
-    return cu_cost(d.NFW, rc, per_cu, resident_workgroups(d.NFW, rc, false));
+    return cu_cost(d.NFW, rc, per_cu, resident_workgroups(d.NFW, rc, false), per_cu > 0 ? L / (double)per_cu : 1.0);
 }
 
 int auto_chunks(const Dims &d, int requested_segments)

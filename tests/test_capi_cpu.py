@@ -171,8 +171,10 @@ def test_tile_size_choice_follows_the_measured_cost_model(built_lib):
     assert rc == 4 and len(tiles) == 2048
     rc, tiles = plan_tiles(_cfg(n_samples=8192, n_elite=819))                       # B5 shard: exactly 5 two-chunk tiles per CU
     assert rc == 2 and len(tiles) == 1280
-    rc, tiles = plan_tiles(_cfg(ensemble_size=15, particles=45, n_samples=500, n_elite=20, horizon=8))   # shipped safe_cem_mpc
-    assert rc == 3
+    rc, tiles = plan_tiles(_cfg(ensemble_size=15, particles=45, n_samples=500, n_elite=20, horizon=8))   # shipped safe_cem_mpc: 22 500 rows
+    assert rc in (2, 3)                                    # (a measured tie: 0.224 / 0.223 ms, tests/test_gpu_tileplan.py; the round-4 table picks 2)
+    rc, tiles = plan_tiles(_cfg(n_samples=1200, n_elite=120))                       # 375 one-chunk tiles: half the CUs carry two (kPartialFill), not 188 two-chunk tiles
+    assert rc == 1 and len(tiles) == 375
 
 
 def test_horizon_segments_are_chosen_where_tiles_do_not_divide_the_cus(built_lib):
