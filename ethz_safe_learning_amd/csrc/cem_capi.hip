@@ -351,6 +351,10 @@ const DeviceFacts &device_facts()
         hipDeviceProp_t pr;
         if (have && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) f.cus = pr.multiProcessorCount;
         else (void)hipGetLastError();
+        // The cost model is per CU (tiles on the busiest CU x the cost of a chunk among k co-resident ones): another CU count only
+        // changes how many tiles a CU gets, not the table.  CEM_ASSUME_CUS=n prices plans for n CUs (a diagnostic: the GPU-less host
+        // helpers and tests/test_capi_cpu.py use it to see the choice move with the CU count; on a device it overrides the real count).
+        if (const char *e = std::getenv("CEM_ASSUME_CUS")) { const int n = std::atoi(e); if (n >= 1 && n <= 4096) f.cus = n; }
     });
     return f;
 }

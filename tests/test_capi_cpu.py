@@ -177,6 +177,24 @@ def test_tile_size_choice_follows_the_measured_cost_model(built_lib):
     assert rc == 1 and len(tiles) == 375
 
 
+def test_tile_size_choice_moves_with_the_cu_count(built_lib):
+    """The cost model is per CU, so it prices a plan for any CU count (cem_capi.hip device_facts: multiProcessorCount; CEM_ASSUME_CUS for
+    the GPU-less helpers): B2's 10 000 rows are 2.4 one-chunk tiles per CU on 256 CUs, but 9.8 on 64 — there larger tiles (fewer weight
+    streams per row) win, and no floating segments are planned when a CU holds more tiles than it keeps resident."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from tests.test_capi_cpu import _cfg; from ethz_safe_learning_amd.planner import plan_tiles, plan_segments; "
+            "c = _cfg(); print(plan_tiles(c)[0], len(plan_tiles(c)[1]), plan_segments(c)[0])" % ROOT)
+    out = {}
+    for cus in (64, 128, 256, 304):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, CEM_ASSUME_CUS=str(cus)), capture_output=True, text=True, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[cus] = tuple(int(x) for x in r.stdout.split())
+    assert out[256] == (1, 625, 6) and out[304][0] == 1            # the shipped device; a few more CUs: still one-chunk tiles
+    assert out[64][0] >= 2 and out[64][2] == 1, out                  # a quarter of the CUs: bigger tiles, plain launch
+    assert out[64][0] >= out[128][0] >= out[256][0], out
+
+
 def test_horizon_segments_are_chosen_where_tiles_do_not_divide_the_cus(built_lib):
     # B2: 625 one-chunk tiles on 256 CUs (3 on the busiest, 2.44 mean): 512 stay whole, 113 float in six 5-step segments
     assert plan_segments(_cfg()) == (6, 5)
