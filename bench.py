@@ -292,7 +292,7 @@ def config_leg(torch, name, obs, act, K, N, H, dev, steps, warmup):
                plan_frac_of_fp32_mfma_peak=I * flops_launch / (dt / steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                select_us_per_iteration=1e3 * sel_ms / max(roll_n, 1),
                kernel=rollout_kernel_name(pl, obs, act), chunks_per_tile=pl.tiles()[0], tiles=int(len(pl.tiles()[1])),
-               horizon_segments=pl.segments()[0], hip_graph=graph)
+               horizon_segments=pl.segments()[0], launches_per_iteration=pl.launches_per_iteration(), hip_graph=graph)
     pl.close()
     return out
 
@@ -547,7 +547,7 @@ def main():
         'config': {'workload': 'B2: obs=60 act=2 K=P=E=5 N=%d H=30 I=5 k=N/10 units=128 layers=4, CemMpc objective, early stop off%s'
                                % (N, '' if G == 1 else ' (weak-scaled: 2000 candidates per GPU, value in B2-equivalent plans/s)'),
                    'candidates_per_gpu': N // G, 'chunks_per_tile': pl.tiles()[0], 'tiles': int(len(pl.tiles()[1])),
-                   'horizon_segments': pl.segments()[0],
+                   'horizon_segments': pl.segments()[0], 'launches_per_iteration': pl.launches_per_iteration(),
                    'hip_graph': pl.graph_status() == 'graph',
                    'exchange': 'none (1 rank)' if not distributed else ('ncclAllGather inside the library, on the planner stream' if native
                                                                       else 'torch.distributed all_gather between ctypes calls'),

@@ -583,6 +583,7 @@ struct cem_planner {
     int n_seg, seg_len, n_pinned;           // horizon segments of the floating tiles (1 = one workgroup per tile), tiles that stay whole
     bool have_weights;
     bool in_plan;
+    bool sample_in_rollout;                  // the sampler runs as the rollout tiles' prologue (else: cem_sample_kernel in front of the rollout launch)
     const float *eps_act, *eps_model;       // current plan's explicit noise (device) or null
     // pinned host staging
     CtrlBlock *h_ctrl;
@@ -720,7 +721,15 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { g_last_hip = (int)hipGetLastError(); delete h; return CEM_ERR_HIP; }
         h->own_stream = true;
     }
-    { const Plan pl = make_plan(cfg, h->d); h->rc = pl.rc; h->n_seg = pl.n_seg; h->seg_len = pl.seg_len; h->n_pinned = pl.n_pinned; }
+    { const Plan pl = make_plan(cfg, h->d); h->rc = pl.rc; h->n_seg = pl.n_seg; h->seg_len = pl.seg_len; h->n_pinned = pl.n_pinned;
+      // Where the sampler runs (cem_device.h: cem_tile_sample_actions vs cem_sample_kernel).  Inside the rollout launch when ALL its
+      // tiles are resident at once (one round of prologues per launch: B1, B2) — one launch and one graph node fewer per iteration for
+      // about what the launch cost; as a launch of its own when tiles queue for slots (B3: 8 tiles per CU; every round of tiles would
+      // pay the prologue on its critical path, and each candidate is sampled once per particle: K = 16 measured +1.5 % on the launch).
+      const int slots = num_cus() * ((h->d.wide || h->d.split) ? 1 : resident_workgroups(h->d.NFW, pl.rc, pl.n_seg > 1));
+      h->sample_in_rollout = pl.n_tiles <= slots;
+      if (const char *e = std::getenv("CEM_FORCE_SAMPLER"))      // diagnostic / tests: "tile" or "kernel" — the results do not depend on it
+          h->sample_in_rollout = std::strcmp(e, "kernel") != 0; }
     h->have_weights = false; h->in_plan = false; h->eps_act = h->eps_model = nullptr;
     h->timing = false; h->roll_ms = h->sel_ms = 0.f; h->roll_n = 0;
     h->graph = nullptr; h->gexec = nullptr; h->graph_ready = false;
@@ -1048,6 +1057,12 @@ int enqueue_rollout(cem_planner *h, int it, bool fold_reduce)
     rp.musig = (const float *)(ws + l.musig); rp.eps_act = h->eps_act ? h->eps_act + (size_t)it * d.N * d.H * d.A : nullptr;
     rp.act_bounds = (const float *)(ws + l.act_bounds); rp.actions_w = (float *)(ws + l.actions); rp.act_pad_w = (float *)(ws + l.act_pad);
     rp.pad_shift = d.O - 4 * d.act_q0; rp.pad_floats = 4 * d.act_nq; rp.N = d.N; rp.Nloc = d.Nloc; rp.n_off = d.n_off; rp.n_tiles = h->n_tiles;
+    if (!h->sample_in_rollout) {                          // all N candidates once, in front of the rollout launch (which then samples nothing)
+        const int total = d.N * d.H * ((d.A + 3) / 4);
+        hipLaunchKernelGGL(cem_sample_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, h->stream, rp);
+        HIPCHK(hipGetLastError());
+        rp.musig = nullptr;
+    }
     size_t e0 = 0;
     if (h->timing) { e0 = h->ev_kind.size() * 2; h->ev_kind.push_back({(int)e0, 0}); hipEventRecord(get_event(h, e0), h->stream); }
     if (d.wide) HIPCHK(launch_rollout_wide(h, rp, h->n_tiles, rp.eps_model ? 1 : 0));
@@ -1363,6 +1378,16 @@ int cem_planner_graph_status(const cem_planner_t *h, int32_t *status_out)
 {
     if (!h || !status_out) return CEM_ERR_INVALID_ARG;
     *status_out = h->graph_ready ? 1 : (h->graph_failed ? 2 : 0);
+    return CEM_OK;
+}
+
+int cem_planner_launches_per_iteration(const cem_planner_t *h, int32_t *launches_out)
+{
+    if (!h || !launches_out) return CEM_ERR_INVALID_ARG;
+    const Dims &d = h->d;
+    const int G = (d.N + CEM_MS_KEYS - 1) / CEM_MS_KEYS;
+    const int mode = resolve_select_mode(h->cfg.select_mode, d.N, d.k, (long long)d.H * d.A, h->sel_dyn_limit, G <= h->fused_resident, nullptr);
+    *launches_out = 1 + (h->sample_in_rollout ? 0 : 1) + (folds_reduce(h) ? 0 : 1) + (mode == 2 ? 8 : 1);
     return CEM_OK;
 }
 

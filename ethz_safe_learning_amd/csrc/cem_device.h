@@ -504,6 +504,23 @@ __device__ __forceinline__ void cem_tile_sample_actions(const RolloutParams &p, 
     if (WAIT) cem_tile_sample_join();
 }
 
+// The same sampler as a launch of its own, over all N candidates once: what a plan uses when its rollout launch runs SEVERAL rounds of
+// tiles per CU or many particles per candidate (the tiles' prologue samples a candidate once per particle and once per round of
+// tiles on the critical path: measured +1.5 % on B3's launch, K = 16, against 0.2 % for this kernel; at B1 / B2 — every tile resident
+// at once, five particles — the prologue costs what this launch plus its graph node cost, and saves the node).  Host rule: cem_capi.hip
+// sample_in_rollout().
+__global__ __launch_bounds__(256) void cem_sample_kernel(const RolloutParams p)
+{
+    if (p.check_done && p.ctrl->done) return;
+    const int AZ = (p.A + 3) >> 2;
+    const int total = p.N * p.H * AZ;
+    const PhiloxKey key = cem_key(p.ctrl);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int z = idx % AZ, t = (idx / AZ) % p.H, n = idx / (AZ * p.H);
+        cem_sample_store(p, n, t, z, key, true);
+    }
+}
+
 // One tile for steps [t_begin, t_end) of the horizon.  SEG false: the whole horizon (t_begin = 0, t_end = H).  SEG true: one
 // segment of it; what a tile carries across a segment boundary (state registers, its next layer-0 input blocks, the bookkeeping
 // wave's reward / done state) goes through p.seg_state, so any workgroup on any CU can run the tile's next segment and the

@@ -294,6 +294,12 @@ class CemPlanner:
         _capi.check(self.lib.cem_planner_graph_status(self.h, C.byref(st)), 'cem_planner_graph_status')
         return ('eager', 'graph', 'graph-unsupported')[st.value]
 
+    def launches_per_iteration(self):
+        """Kernel launches one CEM iteration of plan() takes on this handle (cem_planner_launches_per_iteration)."""
+        n = C.c_int32()
+        _capi.check(self.lib.cem_planner_launches_per_iteration(self.h, C.byref(n)), 'cem_planner_launches_per_iteration')
+        return n.value
+
     def plan_exchange(self):
         _capi.check(self.lib.cem_plan_exchange(self.h), 'cem_plan_exchange')
 

@@ -214,6 +214,12 @@ int cem_plan_exchange(cem_planner_t *h);
 /* 0: cem_planner_plan launches kernel by kernel; 1: it replays a captured hipGraph; 2: capturing was tried and is not supported
  * with this communicator / runtime (the plan then stays kernel by kernel — same results) */
 int cem_planner_graph_status(const cem_planner_t *h, int32_t *status_out);
+/* Kernel launches one CEM iteration of cem_planner_plan takes on this handle (the collective of a sharded plan not counted):
+ * 2 = rollout (its tiles sample their own action sequences, cem_mpc.py:44-48) + select (which forms the particle mean of the CemMpc
+ * objective itself, mpc_policy.py:38-39) — single-rank CemMpc plans whose tiles are all resident at once; + 1 where the sampler is a
+ * launch of its own (tiles queue for slots), + 1 where the reduce kernel stays (SafeCemMpc's Beta filter, sharded plans, the
+ * multi-workgroup selects), + 7 for select_mode 2's chain.  The stepwise calls always launch the reduce kernel. */
+int cem_planner_launches_per_iteration(const cem_planner_t *h, int32_t *launches_out);
 
 /* TransitionModel.unfold_sequences (transition_model.py:64-77) as an API of its own:
  * s0[B][obs], actions[B][H][A] (device) -> traj[B][H+1][obs] (device); optional mu/stddev[B][H][obs].

@@ -38,7 +38,7 @@ def test_default_bench_line():
     assert out.returncode == 0, out.stderr[-2000:]
     r = _json_line(out.stdout)
     _check(r, 5, 2)
-    assert r['config']['hip_graph'] is True
+    assert r['config']['hip_graph'] is True and r['config']['launches_per_iteration'] == 2       # rollout + select per CEM iteration at B2
     # the other BASELINE configs ride along as labelled extras (value stays B2): B1, B3, B4 whole plans + one rank of B5's eight
     cf = r['configs']
     assert set(cf) == {'B1', 'B3', 'B4', 'B5_rank'} and not any('error' in v for v in cf.values()), cf
@@ -49,6 +49,7 @@ def test_default_bench_line():
         assert abs(c['plans_per_s'] * c['ms_per_plan'] / 1e3 - 1.0) < 1e-6 and c['kernel'].startswith('void cem_rollout_')
         assert abs(c['frac_of_fp32_mfma_peak'] - c['algorithmic_flops_per_launch'] / (c['rollout_ms_per_launch'] * 1e-3) / 157.3e12) < 1e-9
         assert (0.25 if name == 'B1' else 0.5) < c['frac_of_fp32_mfma_peak'] < 1.0 and c['plan_frac_of_fp32_mfma_peak'] < c['frac_of_fp32_mfma_peak']
+        assert c['launches_per_iteration'] == (2 if name == 'B1' else 3)      # (B3 / B4: tiles queue for slots — the sampler is a launch of its own)
     assert cf['B5_rank']['candidates_per_rank'] == 8192 and 0.5 < cf['B5_rank']['rollout_frac_of_fp32_mfma_peak_per_rank'] < 1.0
 
 

@@ -519,8 +519,37 @@ def test_plan_philox_equals_plan_on_dumped_noise_and_graph():
     assert not np.array_equal(a4, a3)
 
 
+def test_where_the_sampler_runs_does_not_change_a_plan(monkeypatch):
+    """cem_mpc.py:44-48 runs either as the rollout tiles' prologue (every tile resident at once) or as a launch of its own in front of
+    the rollout (tiles queue for slots): the library picks by the tile plan, CEM_FORCE_SAMPLER overrides.  Same Philox counters, same
+    arithmetic: plans — action, score, mu / sigma, elite set, last actions and scores — are bit-identical either way, at a shape of
+    each kind, and the handle reports the launches an iteration takes."""
+    torch = _torch()
+    pb = hp.make_problem(seed=63)
+    for N, H, k, auto_launches in ((2000, 12, 200, 2), (7000, 6, 700, 3)):       # 625 tiles: resident at once; 2190 tiles: several rounds
+        out = {}
+        for where in ('auto', 'tile', 'kernel'):
+            if where == 'auto':
+                monkeypatch.delenv('CEM_FORCE_SAMPLER', raising=False)
+            else:
+                monkeypatch.setenv('CEM_FORCE_SAMPLER', where)
+            _, cfg = hp.configs(pb, N=N, H=H, P=5, E=5, k=k, I=3, noise=0.02, smoothing=0.1)
+            pl = hp.make_planner(pb, cfg)
+            n_launch = pl.launches_per_iteration()
+            a, s, it = pl.plan(pb['state'], seed=31, call=2)
+            torch.cuda.synchronize()
+            out[where] = (a, s, it, pl.mu_sigma().clone(), pl.elite_idx().clone(), pl.actions().clone(), pl.scores_local().clone(), n_launch)
+            pl.close()
+        assert out['auto'][7] == auto_launches and out['tile'][7] == 2 and out['kernel'][7] == 3, [v[7] for v in out.values()]
+        for where in ('tile', 'kernel'):
+            np.testing.assert_array_equal(out[where][0], out['auto'][0])
+            assert out[where][1:3] == out['auto'][1:3]
+            for i in range(3, 7):
+                assert torch.equal(out[where][i], out['auto'][i]), (N, where, i)
+
+
 @pytest.mark.parametrize('variant,N,H,k,graph', [('cem', 256, 8, 25, False), ('safe', 256, 8, 25, False), ('cem', 2000, 30, 200, True), ('cem', 2000, 30, 200, False),
-                                                 ('safe', 2000, 30, 80, True), ('cem', 500, 25, 50, True)])
+                                                 ('safe', 2000, 30, 80, True), ('cem', 500, 25, 50, True), ('cem', 7000, 6, 700, True)])
 def test_whole_plan_equals_stepwise_plan(variant, N, H, k, graph):
     """cem_planner_plan launches rollout -> select per iteration on a single-rank CemMpc plan (the particle mean is formed by the
     select kernel while it stages its keys); the stepwise calls (cem_plan_rollout / cem_plan_select, what a host-stepped multi-rank
