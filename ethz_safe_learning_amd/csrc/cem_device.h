@@ -381,7 +381,7 @@ __device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], f
         // The wave's two accumulators are blocks 2w and 2w + 1, so the second one visits the wave's own two input blocks swapped
         // (its weights are packed to match).  Every output block thus starts on the input block of the same index, whichever wave
         // computes it: a form of the kernel that spreads the output blocks over more waves sums in the same order (the 8-wave
-        // workgroup of commit 0e0e847 was bit-identical to this kernel — and 1.5 % slower at B1, hence not kept).
+        // workgroup of commit 0e0e847 was bit-identical to this kernel — and 1.5 % slower at B1, hence not kept; profiles/HISTORY.md 4.1).
         const int Pb = (!L0IN && P < 2) ? (P ^ 1) : P;            // (P is a compile-time constant once the loop is unrolled)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

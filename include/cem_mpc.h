@@ -18,6 +18,15 @@
  * throws across the boundary.  A handle is not thread-safe; one plan in flight
  * per handle (the reference has one synchronous caller, simba/agents/agent.py:120).
  * A shape change (scripts/tune_cem_policy.py:109-115) = a new handle.
+ *
+ * Environment variables the library reads (none changes a result; all are diagnostics or deployment overrides):
+ *   CEM_RCCL_LIBRARY=<file>        the RCCL to dlopen instead of librccl.so.1 (a site's build; the tests' shared-memory stand-in).  No
+ *                                  fallback if it does not load; logged on stderr whenever it is honoured.
+ *   CEM_FORCE_SAMPLER=tile|kernel  where cem_mpc.py:44-48 runs: as the rollout tiles' prologue or as a launch of its own (default: by the
+ *                                  tile plan, see cem_planner_launches_per_iteration).
+ *   CEM_ASSUME_CUS=<n>             price tile plans for n compute units (the GPU-less host helpers default to 256; on a device it
+ *                                  overrides multiProcessorCount).
+ *   CEM_FORCE_GENERIC_ROLLOUT      every configuration on the width-generic rollout kernel;  CEM_TRAIN_GEMM_KERNEL: the GEMM-by-GEMM trainer.
  */
 #ifndef CEM_MPC_H
 #define CEM_MPC_H

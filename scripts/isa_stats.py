@@ -4,7 +4,7 @@
   python scripts/isa_stats.py /tmp/isa/cem.s 'cem_rollout_kernelILi1ELi1ELi0' [--blocks]
 
 Prints, per basic block that holds MFMAs (or all of them with --blocks), the number of MFMA / VALU (by class) / LDS / VMEM /
-SALU instructions.  Used to see what sits next to the fp32 MFMAs in the rollout kernels (DESIGN 4.1): every VALU instruction
+SALU instructions.  Used to see what sits next to the fp32 MFMAs in the rollout kernels (DESIGN.md 4.1): every VALU instruction
 there is paid in full.
 """
 import collections
