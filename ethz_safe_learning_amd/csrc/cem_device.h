@@ -1280,6 +1280,35 @@ __device__ __forceinline__ void cem_block_excl_scan2(const uint32_t a, const uin
     pa = ba + ia - a; pb = bb + ib - b;
 }
 
+// block-wide (1024 threads): the bin b with ge[b] >= need > ge[b + 1], ge[b] = #keys in bins >= b; returns (b, need - ge[b + 1])
+// COHERENT: the histogram was written by other workgroups of the SAME kernel (atomics at the device coherence point): read it there too
+template <bool COHERENT = false>
+__device__ __forceinline__ void cem_ms_find(const uint32_t *h, const int nbins, const uint32_t need, uint32_t *sh /* [20] */, uint32_t &bin, uint32_t &need_next)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b0 = 2 * tid, b1 = 2 * tid + 1;
+    uint32_t h0 = 0u, h1 = 0u;
+    if (COHERENT) {
+        if (b0 < nbins) h0 = __hip_atomic_load(h + b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b1 < nbins) h1 = __hip_atomic_load(h + b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else { h0 = b0 < nbins ? h[b0] : 0u; h1 = b1 < nbins ? h[b1] : 0u; }
+    const uint32_t tot = h0 + h1;
+    uint32_t inc = tot;                                   // inclusive prefix over lower thread ids
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+    if (lane == 63) sh[wv] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (int i = 0; i < 16; ++i) { const uint32_t v = sh[i]; all += v; if (i < wv) before += v; }
+    const uint32_t above = all - (before + inc);          // keys in bins of higher thread ids
+    const uint32_t ge1 = h1 + above, ge0 = tot + above;
+    if (ge1 >= need && above < need) { sh[16] = (uint32_t)b1; sh[17] = need - above; }
+    if (ge0 >= need && ge1 < need) { sh[16] = (uint32_t)b0; sh[17] = need - ge1; }
+    __syncthreads();
+    bin = sh[16]; need_next = sh[17];
+    __syncthreads();
+}
+
 // top_k + best-so-far + moments + smoothing + early stop, one 1024-thread workgroup  (cem_mpc.py:56-67).
 // One CU, so the kernel is a latency chain: the scores are staged in LDS once (CACHE; they are read by 4 radix passes, the
 // compaction and the best-of-elite), the 256-bin suffix scan of a pass is done by one wave with shuffles (2 barriers per
@@ -1290,7 +1319,8 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
     extern __shared__ __attribute__((aligned(16))) char sel_smem[];
     __shared__ __attribute__((aligned(16))) uint32_t hist[2][256];
     __shared__ uint32_t wsum[2][16];
-    __shared__ uint32_t sh_prefix, sh_need;
+    __shared__ uint32_t sh_prefix, sh_need, sh_cnt;
+    __shared__ uint32_t sh20[20];
     __shared__ __attribute__((aligned(16))) float red[4096];   // per-thread partial sums (float4 in the wide moments path)
     __shared__ float bsc[16];
     __shared__ int bpos[16];
@@ -1367,10 +1397,58 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
     }
     CEM_SEL_STAMP(1);
 
-    // ---- radix select of the k-th largest key ----------------------------------------------------------
+    // ---- the k-th largest key -------------------------------------------------------------------------------
     uint32_t prefix = 0, mask = 0, need = (uint32_t)k;
+    bool solved = false;
+    if (CACHE) {
+        // Bucket select on the range the keys actually span (round 4).  The scores of an iteration sit in a narrow band (same sign,
+        // an exponent or two), so 2048 buckets of [kmin, kmax] — bucket = (key - base) >> sh, monotone in the key — usually leave a
+        // handful of keys in the k-th key's bucket; those are ranked against each other directly (key descending, candidate index
+        // ascending: tf.nn.top_k's tie order).  A bucket that still holds more than 256 keys (SafeCemMpc: hundreds of scores crowd
+        // around -100) is split again, 11 bits finer, until it is small or one key wide (sh = 0: all its keys are equal).  At most
+        // three levels; typically ONE atomic pass + one block-wide scan + a rank over a few keys, where the byte-wide radix took
+        // three passes of an atomic pass, a one-wave scan and three barriers each.  Same T, same `need`: the compaction is unchanged.
+        uint32_t *h2k = reinterpret_cast<uint32_t *>(red);               // [2048] bucket counts   (the moments' scratch: not in use yet)
+        uint32_t *lkey = h2k + 2048, *lidx = lkey + 1024;                // the k-th key's bucket: keys, candidate indices
+        uint32_t base = kmin, window = kmax - kmin;                      // keys in play: base <= key <= base + window
+        int sh = window ? max(0, 21 - (int)__clz((int)window)) : 0;      // window >> sh < 2048
+#pragma unroll 1
+        for (int level = 0; level < 4; ++level) {
+            h2k[tid] = 0u; h2k[tid + 1024] = 0u;
+            if (tid == 0) sh_cnt = 0u;
+            __syncthreads();
+            for (int i = tid; i < N; i += 1024) {
+                const uint32_t off = ckey[CEM_SEL_KIDX(i)] - base;      // (a key below base wraps to a huge offset: out of the window)
+                if (off <= window) atomicAdd(&h2k[off >> sh], 1u);
+            }
+            __syncthreads();
+            uint32_t bucket, need1;
+            cem_ms_find<false>(h2k, 2048, need, sh20, bucket, need1);   // ge[bucket] >= need > ge[bucket + 1]; need1 = need - ge[bucket + 1]
+            const uint32_t m = h2k[bucket];
+            if (sh == 0) { prefix = base + bucket; need = need1; solved = true; break; }     // the bucket is ONE key: `need1` of its ties are taken
+            if (m <= 256u) {                                             // (workgroup-uniform)
+                for (int i = tid; i < N; i += 1024) {
+                    const uint32_t key = ckey[CEM_SEL_KIDX(i)], off = key - base;
+                    if (off <= window && (off >> sh) == bucket) { const uint32_t pos = atomicAdd(&sh_cnt, 1u); lkey[pos] = key; lidx[pos] = (uint32_t)i; }
+                }
+                __syncthreads();
+                if ((uint32_t)tid < m) {
+                    const uint32_t kj = lkey[tid], ij = lidx[tid];
+                    uint32_t gt = 0, before = 0;
+                    for (uint32_t l = 0; l < m; ++l) { const uint32_t kl = lkey[l]; gt += kl > kj; before += (kl > kj) || (kl == kj && lidx[l] < ij); }
+                    if (before == need1 - 1u) { sh_prefix = kj; sh_need = need1 - gt; }     // the k-th largest; ties at its key still to take
+                }
+                __syncthreads();
+                prefix = sh_prefix; need = sh_need; solved = true;
+                break;
+            }
+            base += bucket << sh; window = (1u << sh) - 1u; need = need1;    // split that bucket, 11 bits finer
+            sh = sh > 11 ? sh - 11 : 0;
+            __syncthreads();                                             // (h2k / sh20 are rewritten by the next level)
+        }
+    }
     bool leading = true;
-    for (int pass = 3; pass >= 0; --pass) {
+    for (int pass = solved ? -1 : 3; pass >= 0; --pass) {
         const int hb = pass & 1;
         if (leading && ((kdiff >> (8 * pass)) & 255u) == 0u) {             // every key has this byte (workgroup-uniform test)
             prefix |= kmin & (0xFFu << (8 * pass)); mask |= 0xFFu << (8 * pass);
@@ -1634,35 +1712,6 @@ struct MSelParams {
     float smoothing, one_minus_smoothing, threshold;   // one_minus_smoothing = fl32(1.0 - smoothing) rounded once, as cem_mpc.py:64-65 does
     uint32_t *bar;                    // cem_msel_fused_kernel: arrival counter of its grid barriers (zeroed with the histograms)
 };
-
-// block-wide (1024 threads): the bin b with ge[b] >= need > ge[b + 1], ge[b] = #keys in bins >= b; returns (b, need - ge[b + 1])
-// COHERENT: the histogram was written by other workgroups of the SAME kernel (atomics at the device coherence point): read it there too
-template <bool COHERENT = false>
-__device__ __forceinline__ void cem_ms_find(const uint32_t *h, const int nbins, const uint32_t need, uint32_t *sh /* [20] */, uint32_t &bin, uint32_t &need_next)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int b0 = 2 * tid, b1 = 2 * tid + 1;
-    uint32_t h0 = 0u, h1 = 0u;
-    if (COHERENT) {
-        if (b0 < nbins) h0 = __hip_atomic_load(h + b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (b1 < nbins) h1 = __hip_atomic_load(h + b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else { h0 = b0 < nbins ? h[b0] : 0u; h1 = b1 < nbins ? h[b1] : 0u; }
-    const uint32_t tot = h0 + h1;
-    uint32_t inc = tot;                                   // inclusive prefix over lower thread ids
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
-    if (lane == 63) sh[wv] = inc;
-    __syncthreads();
-    uint32_t before = 0, all = 0;
-    for (int i = 0; i < 16; ++i) { const uint32_t v = sh[i]; all += v; if (i < wv) before += v; }
-    const uint32_t above = all - (before + inc);          // keys in bins of higher thread ids
-    const uint32_t ge1 = h1 + above, ge0 = tot + above;
-    if (ge1 >= need && above < need) { sh[16] = (uint32_t)b1; sh[17] = need - above; }
-    if (ge0 >= need && ge1 < need) { sh[16] = (uint32_t)b0; sh[17] = need - ge1; }
-    __syncthreads();
-    bin = sh[16]; need_next = sh[17];
-    __syncthreads();
-}
 
 template <int PASS>
 __global__ __launch_bounds__(1024) void cem_msel_hist_kernel(const MSelParams p)
