@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -588,6 +589,7 @@ struct cem_planner {
     // pinned host staging
     CtrlBlock *h_ctrl;
     float *h_result;
+    uint32_t plan_seq;                       // plans staged on this handle (CtrlBlock::seq)
     const CtrlBlock *d_h_ctrl; float *d_h_result;     // the same two blocks as the DEVICE addresses them (hipHostGetDevicePointer)
     // timing
     bool timing; std::vector<hipEvent_t> ev; float roll_ms, sel_ms; int roll_n;
@@ -735,7 +737,7 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
     h->graph = nullptr; h->gexec = nullptr; h->graph_ready = false;
     h->comm = nullptr; h->plans_since_comm = 0; h->graph_failed = false;
     h->h_ctrl = nullptr; h->h_result = nullptr;
-    h->scratch = nullptr; h->scratch_bytes = 0; h->sel_zeroed = false;
+    h->scratch = nullptr; h->scratch_bytes = 0; h->sel_zeroed = false; h->plan_seq = 0;
     // every failure from here on frees what was acquired and reports the HIP code
     auto fail = [&](int status) {
         g_last_hip = (int)hipGetLastError();
@@ -1154,6 +1156,7 @@ int enqueue_select(cem_planner *h, int it, bool fold_reduce, bool fold_final = f
         }
     } else {
         if (fold_final) {
+            p.is_last = it == d.I - 1;
             p.result = h->d_h_result; p.eps_out = have_eps_out ? (const float *)(ws + l.eps_out) : nullptr; p.noise_stddev = h->cfg.noise_stddev;
             if (folded) *folded = true;
         }
@@ -1206,6 +1209,25 @@ void stage_ctrl(cem_planner *h, const float *state, uint64_t seed, uint64_t call
     c->done = 0; c->iters = 0; c->fault = 0; c->best_score = -std::numeric_limits<float>::infinity();
     for (int f = 0; f < CEM_U; ++f) c->state[f] = f < h->d.O ? state[f] : 0.f;
     for (int a = 0; a < 32; ++a) c->best[a] = 0.f;
+    c->seq = ++h->plan_seq;                             // echoed into result[36] by the kernel that completes the plan
+}
+
+// The plan is queued: wait for its result.  The kernel that completes it stores the plan counter into pinned host memory after
+// everything else of the result, so the host watches that word — a few hundred nanoseconds after the store — instead of going
+// through hipStreamSynchronize (an interrupt / yield path that took ~10 us of a 1.9-ms plan).  Bounded: after ~50 ms of polling (a
+// plan that long is not latency-critical; a faulted device never writes the word) the ordinary synchronisation takes over.
+int wait_result(cem_planner *h)
+{
+    volatile uint32_t *marker = reinterpret_cast<volatile uint32_t *>(h->h_result) + 36;
+    const uint32_t want = h->plan_seq;
+    for (long spin = 0; spin < 20000000l; ++spin) {
+        if (*marker == want) { std::atomic_thread_fence(std::memory_order_acquire); return CEM_OK; }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CEM_OK;
 }
 
 int read_result(cem_planner *h, float *action_out, float *best_score_out, int32_t *iters_out)
@@ -1299,7 +1321,7 @@ int cem_planner_plan(cem_planner_t *h, const float *state, uint64_t seed, uint64
         }
         if (h->graph_ready) {
             HIPCHK(hipGraphLaunch(h->gexec, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
+            { const int ws_ = wait_result(h); if (ws_) return ws_; }
             return read_result(h, action_out, best_score_out, iters_out);
         }
     }

@@ -68,6 +68,8 @@ struct CtrlBlock {
     int32_t fault;           // set by a kernel that had to give up (cem_rollout_seg_kernel's bounded spin); reported as CEM_ERR_DEVICE
     float state[CEM_U];      // the observation (cem_mpc.py:32)
     float best[32];          // best_so_far (cem_mpc.py:41)
+    uint32_t seq;            // the host's plan counter: the kernel that completes the plan's result echoes it into result[36] LAST, so
+                             // the host can watch pinned memory for it instead of going through a stream synchronisation
 };
 
 struct ScorerDev {
@@ -1220,6 +1222,7 @@ struct SelectParams {
     const float *ret; float *scores_w; int32_t P;
     // the plan's result written by the select itself (whole plans on this kernel: no final kernel; see FinalParams): null = not here
     float *result; const float *eps_out; float noise_stddev;
+    int32_t is_last;             // this is the plan's last iteration: with `result`, the completion marker (result[36] = ctrl->seq) follows the result
     int32_t N, k, HA, A, check_done;
     float smoothing, one_minus_smoothing, threshold;   // one_minus_smoothing = fl32(1.0 - smoothing) rounded once, as cem_mpc.py:64-65 does
     long long *stamps;           // [8] section stamps of -DCEM_STAMPS diagnostic builds
@@ -1646,6 +1649,7 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
     }
     }
     CEM_SEL_STAMP(5);
+    bool plan_complete = false;                              // (thread 0 only) this select's result is the plan's
     if (tid == 0) {
         float ssum = 0.f;
         for (int i = 0; i < HA; ++i) ssum = ssum + newsig[i];
@@ -1658,6 +1662,7 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
             reinterpret_cast<int32_t *>(p.result)[33] = iters;
             reinterpret_cast<int32_t *>(p.result)[34] = stop ? 1 : p.ctrl->done;
             reinterpret_cast<int32_t *>(p.result)[35] = p.ctrl->fault;
+            plan_complete = stop || p.is_last != 0;
         }
         CEM_SEL_STAMP(6);
     }
@@ -1684,6 +1689,13 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
         }
         if (better) p.ctrl->best_score = bs;
         if (p.result) p.result[32] = better ? bs : p.ctrl->best_score;
+    }
+    if (p.result) {
+        // the completion marker goes out after every part of the result (two threads wrote it): system-scope fence, barrier, then the
+        // echo of the host's plan counter — the host polls that word in pinned memory (cem_capi.hip wait_result)
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0 && plan_complete) __hip_atomic_store(reinterpret_cast<uint32_t *>(p.result) + 36, p.ctrl->seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -2121,6 +2133,9 @@ __global__ void cem_final_kernel(const FinalParams p)
         reinterpret_cast<int32_t *>(p.result)[34] = p.ctrl->done;
         reinterpret_cast<int32_t *>(p.result)[35] = p.ctrl->fault;
     }
+    __threadfence_system();
+    __syncthreads();
+    if (a == 0) __hip_atomic_store(reinterpret_cast<uint32_t *>(p.result) + 36, p.ctrl->seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // the raw Philox4x32-7 words of n counters (idx0 + i, t | it << 16, sub | stream << 16, call_lo) — what cem_normal4 turns into four
