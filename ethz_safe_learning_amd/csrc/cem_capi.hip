@@ -1216,12 +1216,20 @@ void stage_ctrl(cem_planner *h, const float *state, uint64_t seed, uint64_t call
 // everything else of the result, so the host watches that word — a few hundred nanoseconds after the store — instead of going
 // through hipStreamSynchronize (an interrupt / yield path that took ~10 us of a 1.9-ms plan).  Bounded: after ~50 ms of polling (a
 // plan that long is not latency-critical; a faulted device never writes the word) the ordinary synchronisation takes over.
+// the block is complete when it carries this plan's counter AND its checksum holds (device -> host writes arrive in no particular order)
+bool result_landed(const cem_planner *h)
+{
+    const volatile uint32_t *r = reinterpret_cast<const volatile uint32_t *>(h->h_result);
+    if (r[36] != h->plan_seq) return false;
+    uint32_t x = CEM_RESULT_MAGIC ^ h->plan_seq;
+    for (int i = 0; i < 36; ++i) x ^= r[i];
+    return x == r[37];
+}
+
 int wait_result(cem_planner *h)
 {
-    volatile uint32_t *marker = reinterpret_cast<volatile uint32_t *>(h->h_result) + 36;
-    const uint32_t want = h->plan_seq;
     for (long spin = 0; spin < 20000000l; ++spin) {
-        if (*marker == want) { std::atomic_thread_fence(std::memory_order_acquire); return CEM_OK; }
+        if (result_landed(h)) { std::atomic_thread_fence(std::memory_order_acquire); return CEM_OK; }
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif
@@ -1232,6 +1240,9 @@ int wait_result(cem_planner *h)
 
 int read_result(cem_planner *h, float *action_out, float *best_score_out, int32_t *iters_out)
 {
+    // (after a stream synchronisation the block has landed; the check costs nothing and a short wait covers a write still in flight)
+    for (int spin = 0; spin < 2000000 && !result_landed(h); ++spin) { }
+    if (!result_landed(h)) return CEM_ERR_DEVICE;
     if (action_out) std::memcpy(action_out, h->h_result, h->d.A * 4);
     if (best_score_out) *best_score_out = h->h_result[32];
     if (iters_out) *iters_out = reinterpret_cast<int32_t *>(h->h_result)[33];

@@ -1215,6 +1215,23 @@ __device__ __forceinline__ float cem_out_noise(const CtrlBlock *ctrl, const floa
 }
 
 
+// The plan's result as the HOST reads it from pinned memory: words [0, A) action, [32] score, [33] iterations run, [34] early-stop flag,
+// [35] fault bits, [36] the host's plan counter (CtrlBlock::seq), [37] the XOR of words 0..36 and a constant.  The host may poll for word
+// 36 instead of synchronising the stream, and writes to host memory from the device are NOT ordered with one another on the way (a
+// marker stored after the data — even behind a barrier and the stores' acknowledgements — was seen BEFORE the data: measured), so the
+// block carries a checksum and the host accepts it only when counter and checksum both match.  One wave stores the block from an LDS copy.
+#define CEM_RESULT_WORDS 38
+#define CEM_RESULT_MAGIC 0x5EC0DE5Au
+__device__ __forceinline__ void cem_emit_result(float *result, const uint32_t *res_l /* LDS [36] */, const uint32_t seq, const int lane)
+{
+    uint32_t x = CEM_RESULT_MAGIC ^ seq;
+    for (int i = 0; i < 36; ++i) x ^= res_l[i];
+    if (lane < CEM_RESULT_WORDS) {
+        const uint32_t w = lane < 36 ? res_l[lane] : (lane == 36 ? seq : x);
+        __hip_atomic_store(reinterpret_cast<uint32_t *>(result) + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 struct SelectParams {
     const float *scores; const float *actions; float *musig; CtrlBlock *ctrl; int32_t *elite_idx;
     // the particle mean of the CemMpc objective folded into the key staging (single-rank whole plans; null: read `scores`):
@@ -1649,7 +1666,9 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
     }
     }
     CEM_SEL_STAMP(5);
-    bool plan_complete = false;                              // (thread 0 only) this select's result is the plan's
+    uint32_t *res_l = reinterpret_cast<uint32_t *>(red);     // [36] the plan's result in the making + [36] "this select completes the plan"  (LDS: the moments are done with `red`)
+    if (p.result && tid < 37) res_l[tid] = 0u;
+    if (p.result) __syncthreads();
     if (tid == 0) {
         float ssum = 0.f;
         for (int i = 0; i < HA; ++i) ssum = ssum + newsig[i];
@@ -1658,11 +1677,9 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
         const bool stop = mean_sigma <= p.threshold;                                          // cem_mpc.py:66-67
         p.ctrl->iters = iters;
         if (stop) p.ctrl->done = 1;
-        if (p.result) {             // (every iteration leaves the result as it stands: the last select that RUNS is the plan's last word)
-            reinterpret_cast<int32_t *>(p.result)[33] = iters;
-            reinterpret_cast<int32_t *>(p.result)[34] = stop ? 1 : p.ctrl->done;
-            reinterpret_cast<int32_t *>(p.result)[35] = p.ctrl->fault;
-            plan_complete = stop || p.is_last != 0;
+        if (p.result) {             // (the select that ends the plan — its last iteration or the early stop — hands the result to the host)
+            res_l[33] = (uint32_t)iters; res_l[34] = stop ? 1u : (uint32_t)p.ctrl->done; res_l[35] = (uint32_t)p.ctrl->fault;
+            res_l[36] = (stop || p.is_last != 0) ? 1u : 0u;
         }
         CEM_SEL_STAMP(6);
     }
@@ -1683,19 +1700,16 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
                 if (a < p.A) {
                     const float b = better ? p.actions[(size_t)idx * HA + a] : p.ctrl->best[a];     // first step's action
                     if (better) p.ctrl->best[a] = b;
-                    if (p.result) p.result[a] = b + (p.eps_out ? p.eps_out[a] : e[r]) * p.noise_stddev;   // cem_mpc.py:68
+                    if (p.result) res_l[a] = __float_as_uint(b + (p.eps_out ? p.eps_out[a] : e[r]) * p.noise_stddev);   // cem_mpc.py:68
                 }
             }
         }
         if (better) p.ctrl->best_score = bs;
-        if (p.result) p.result[32] = better ? bs : p.ctrl->best_score;
+        if (p.result) res_l[32] = __float_as_uint(better ? bs : p.ctrl->best_score);
     }
     if (p.result) {
-        // the completion marker goes out after every part of the result (two threads wrote it): system-scope fence, barrier, then the
-        // echo of the host's plan counter — the host polls that word in pinned memory (cem_capi.hip wait_result)
-        __threadfence_system();
         __syncthreads();
-        if (tid == 0 && plan_complete) __hip_atomic_store(reinterpret_cast<uint32_t *>(p.result) + 36, p.ctrl->seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid < 64 && res_l[36]) cem_emit_result(p.result, res_l, p.ctrl->seq, tid);
     }
 }
 
@@ -2125,17 +2139,17 @@ struct FinalParams { const CtrlBlock *ctrl; const float *eps_out; float *result;
 
 __global__ void cem_final_kernel(const FinalParams p)
 {
+    __shared__ uint32_t res_l[40];
     const int a = threadIdx.x;
-    if (a < p.A) p.result[a] = p.ctrl->best[a] + cem_out_noise(p.ctrl, p.eps_out, a) * p.noise_stddev;   // cem_mpc.py:68
-    if (a == 0) {
-        p.result[32] = p.ctrl->best_score;
-        reinterpret_cast<int32_t *>(p.result)[33] = p.ctrl->iters;
-        reinterpret_cast<int32_t *>(p.result)[34] = p.ctrl->done;
-        reinterpret_cast<int32_t *>(p.result)[35] = p.ctrl->fault;
-    }
-    __threadfence_system();
+    if (a < 36) res_l[a] = 0u;
     __syncthreads();
-    if (a == 0) __hip_atomic_store(reinterpret_cast<uint32_t *>(p.result) + 36, p.ctrl->seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a < p.A) res_l[a] = __float_as_uint(p.ctrl->best[a] + cem_out_noise(p.ctrl, p.eps_out, a) * p.noise_stddev);   // cem_mpc.py:68
+    if (a == 0) {
+        res_l[32] = __float_as_uint(p.ctrl->best_score);
+        res_l[33] = (uint32_t)p.ctrl->iters; res_l[34] = (uint32_t)p.ctrl->done; res_l[35] = (uint32_t)p.ctrl->fault;
+    }
+    __syncthreads();
+    if (a < 64) cem_emit_result(p.result, res_l, p.ctrl->seq, a);
 }
 
 // the raw Philox4x32-7 words of n counters (idx0 + i, t | it << 16, sub | stream << 16, call_lo) — what cem_normal4 turns into four
