@@ -8,6 +8,7 @@
 #include "../../include/cem_mpc.h"
 
 #include <dlfcn.h>
+#include <link.h>
 
 #include <algorithm>
 #include <atomic>
@@ -18,6 +19,7 @@
 #include <limits>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 static thread_local int g_last_hip = 0;
@@ -572,6 +574,33 @@ const int kNcclFloat32 = 7;        // ncclDataType_t ncclFloat32 (rccl.h)
 }  // namespace
 #define NCCLCHK(x) do { int e_ = (x); if (e_ != 0) { g_last_hip = e_; return CEM_ERR_COMM; } } while (0)
 
+// A host that loads this library BEFORE the HIP runtime that owns its device memory (torch's wheel carries its own libamdhip64) ends up
+// with two runtimes in the process: pointers from one are foreign to the other and the first call fails with hipErrorNoDevice or worse
+// (INTEGRATION.md section 2).  The Python binding avoids it by importing torch first; any other host gets told, once, at its first create.
+namespace {
+int count_hip_runtimes(struct dl_phdr_info *info, size_t, void *data)
+{
+    if (info->dlpi_name && std::strstr(info->dlpi_name, "libamdhip64")) {
+        auto *v = static_cast<std::vector<std::string> *>(data);
+        if (std::find(v->begin(), v->end(), std::string(info->dlpi_name)) == v->end()) v->push_back(info->dlpi_name);
+    }
+    return 0;
+}
+void warn_if_two_hip_runtimes()
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        std::vector<std::string> libs;
+        dl_iterate_phdr(count_hip_runtimes, &libs);
+        if (libs.size() > 1) {
+            std::fprintf(stderr, "cem_mpc: %zu HIP runtimes are loaded in this process:", libs.size());
+            for (const auto &l : libs) std::fprintf(stderr, " %s", l.c_str());
+            std::fprintf(stderr, "\ncem_mpc: device memory and streams of one are foreign to the other — load libcem_mpc_gfx950.so AFTER the runtime that owns them (INTEGRATION.md)\n");
+        }
+    });
+}
+}  // namespace
+
 struct cem_planner {
     cem_config_t cfg;
     Dims d;
@@ -713,6 +742,7 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
 {
     int st = validate(cfg); if (st) return st;
     if (!workspace || !out) return CEM_ERR_INVALID_ARG;
+    warn_if_two_hip_runtimes();
     cem_planner *h = new (std::nothrow) cem_planner();
     if (!h) return CEM_ERR_INVALID_ARG;
     h->cfg = *cfg; h->d = make_dims(cfg);

@@ -455,7 +455,8 @@ __device__ __forceinline__ void cem_scorer_terms(const f4 sn, const float D, con
 // select still runs over ALL N candidates, so the tiles also share out the sequences of the OTHER ranks' candidates (`actions` only):
 // tile b of n_tiles takes the b-th slice of those (N - Nloc) * H * ceil(A / 4) draws.  With this the sampler costs no launch of its own
 // (it was 4.8 us + a graph-node gap per iteration at B2).  The caller waits (vmcnt(0)) and barriers before the first action load.
-__device__ __forceinline__ void cem_sample_store(const RolloutParams &p, const int n, const int t, const int z, const PhiloxKey key, const bool pad)
+__device__ __forceinline__ void cem_sample_store(const RolloutParams &p, const int n, const int t, const int z, const PhiloxKey key, const bool pad,
+                                                 const bool natural = true)
 {
     const int A = p.A, HA = p.H * A;
     f4 e;
@@ -469,7 +470,7 @@ __device__ __forceinline__ void cem_sample_store(const RolloutParams &p, const i
         if (a < A) {
             float v = e[r] * p.musig[HA + t * A + a] + p.musig[t * A + a];             // tf.random.normal(mean, stddev)
             v = fminf(fmaxf(v, p.act_bounds[a]), p.act_bounds[32 + a]);                // tf.clip_by_value
-            p.actions_w[((size_t)n * p.H + t) * A + a] = v;
+            if (natural) p.actions_w[((size_t)n * p.H + t) * A + a] = v;
             if (pad) p.act_pad_w[((size_t)n * p.H + t) * p.pad_floats + p.pad_shift + a] = v;   // padding words stay 0 (zeroed at create)
         }
     }
@@ -481,17 +482,21 @@ __device__ __forceinline__ void cem_tile_sample_join()
     __syncthreads();
 }
 // WAIT false: the stores are only issued; the caller joins (cem_tile_sample_join) once the rest of its tile set-up is issued too
+// natural_all: every tile also stores its candidates in the [N][H][A] layout (the explicit-tensor rollout forms read that one back);
+// otherwise only the tiles of particle 0 do — the select is its only reader then, and P - 1 of P copies were 2 MB of stores a launch
 template <bool WAIT = true>
-__device__ __forceinline__ void cem_tile_sample_actions(const RolloutParams &p, const int tile_idx, const int t0, const int t1, const bool foreign)
+__device__ __forceinline__ void cem_tile_sample_actions(const RolloutParams &p, const int tile_idx, const int t0, const int t1, const bool foreign,
+                                                        const bool natural_all = true)
 {
     if (!p.musig) return;                                    // wave-uniform (a kernel argument)
     const TileDesc td = p.tiles[tile_idx];
+    const bool natural = natural_all || td.row_base < p.Nloc;
     const int AZ = (p.A + 3) >> 2, nst = t1 - t0;
     const PhiloxKey key = cem_key(p.ctrl);
     const int own = td.cnt * nst * AZ;
     for (int idx = (int)threadIdx.x; idx < own; idx += 256) {
         const int z = idx % AZ, tt = (idx / AZ) % nst, r_ = idx / (AZ * nst);
-        cem_sample_store(p, td.act_base + r_, t0 + tt, z, key, true);
+        cem_sample_store(p, td.act_base + r_, t0 + tt, z, key, true, natural);
     }
     if (foreign && p.Nloc < p.N) {                           // the other ranks' candidates, shared out over this rank's tiles
         const long long total = (long long)(p.N - p.Nloc) * p.H * AZ;
@@ -936,7 +941,7 @@ __global__ __launch_bounds__(256) void cem_rollout_kernel(const RolloutParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (p.check_done && p.ctrl->done) return;
-    cem_tile_sample_actions<false>(p, (int)blockIdx.x, 0, p.H, true);
+    cem_tile_sample_actions<false>(p, (int)blockIdx.x, 0, p.H, true, MODE == 1);
     cem_rollout_tile<RC, NFW, MODE, false>(p, smem, (int)blockIdx.x, 0, p.H);
 }
 
@@ -961,7 +966,7 @@ __global__ __launch_bounds__(256) void cem_rollout_seg_kernel(const RolloutParam
     __shared__ uint32_t item_s;
     if (p.check_done && p.ctrl->done) return;
     if ((int)blockIdx.x < p.n_pinned) {
-        cem_tile_sample_actions<false>(p, (int)blockIdx.x, 0, p.H, true);
+        cem_tile_sample_actions<false>(p, (int)blockIdx.x, 0, p.H, true, false);
         cem_rollout_tile<RC, NFW, 0, true>(p, smem, (int)blockIdx.x, 0, p.H);
         return;
     }
@@ -990,7 +995,7 @@ __global__ __launch_bounds__(256) void cem_rollout_seg_kernel(const RolloutParam
     const int t0 = seg * p.seg_len, t1 = (t0 + p.seg_len < p.H) ? t0 + p.seg_len : p.H;
     // every segment samples the steps IT reads (the epilogue of step t fetches the action of step t + 1): a floating tile's segments
     // run on different CUs, and nothing sampled by one workgroup is read by another
-    cem_tile_sample_actions<false>(p, tile, t0, t1 < p.H ? t1 + 1 : p.H, seg == 0);
+    cem_tile_sample_actions<false>(p, tile, t0, t1 < p.H ? t1 + 1 : p.H, seg == 0, false);
     cem_rollout_tile<RC, NFW, 0, true>(p, smem, tile, t0, t1);
     if (t1 == p.H) {
         // the launch's last floating tile leaves the work queue as the next launch needs it (all items have run by then: every ticket

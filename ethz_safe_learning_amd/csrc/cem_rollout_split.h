@@ -418,6 +418,6 @@ __global__ __launch_bounds__(256) void cem_rollout_split_kernel(const RolloutPar
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (p.check_done && p.ctrl->done) return;
-    cem_tile_sample_actions(p, (int)blockIdx.x, 0, p.H, true);
+    cem_tile_sample_actions(p, (int)blockIdx.x, 0, p.H, true, MODE == 1);
     cem_rollout_tile_split<RC, NFW, MODE>(p, smem, (int)blockIdx.x);
 }

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void cem_rollout_wide_kernel(const WidePara
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RolloutParams &p = wp.r;
     if (p.check_done && p.ctrl->done) return;
-    cem_tile_sample_actions(p, (int)blockIdx.x, 0, p.H, true);
+    cem_tile_sample_actions(p, (int)blockIdx.x, 0, p.H, true, MODE == 1);
     constexpr int RC = 1, NFW = 2;                         // 16-row tiles; obs + act <= 128: a wave owns input blocks w and w + 4
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);

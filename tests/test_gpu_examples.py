@@ -31,3 +31,32 @@ def test_build_then_smoke_in_one_fresh_process():
     r = subprocess.run([sys.executable, '-c', 'import __graft_entry__ as g; g.build(); g.smoke(); print("both ok")'], cwd=ROOT,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and 'both ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_a_host_that_loads_the_library_before_its_hip_runtime_is_told():
+    """The trap behind the test above, for a host that is not this repo's Python binding: dlopen libcem_mpc_gfx950.so FIRST (it pulls
+    in /opt/rocm's libamdhip64), then bring the runtime that owns the device memory (torch's copy) — two HIP runtimes in one process.
+    The first cem_planner_create says so on stderr (cem_capi.hip warn_if_two_hip_runtimes), whatever the call then returns."""
+    import subprocess
+    code = r'''
+import ctypes as C, os, sys
+root = %r
+sys.path.insert(0, root)
+lib_path = os.path.join(root, 'ethz_safe_learning_amd', 'lib', 'libcem_mpc_gfx950.so')
+C.CDLL(lib_path)                                   # before torch: the wrong order
+import torch
+from ethz_safe_learning_amd import _capi
+from tests import helpers as hp
+pb = hp.make_problem(seed=1)
+_, cfg = hp.configs(pb, N=32, H=3, P=5, E=5, k=4, I=1)
+try:
+    hp.make_planner(pb, cfg)
+    print('create ok')
+except Exception as e:
+    print('create failed:', type(e).__name__)
+''' % ROOT
+    r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert 'create ok' in r.stdout or 'create failed' in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+    n_runtimes = r.stderr.count('libamdhip64')
+    if 'create failed' in r.stdout or n_runtimes:
+        assert 'HIP runtimes are loaded in this process' in r.stderr, r.stderr[-2000:]
