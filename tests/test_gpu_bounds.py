@@ -95,7 +95,8 @@ def test_sampling_params_reach_the_device(name):
     mu, sigma, best, best_score, elite, stop = o.select_and_refit(scores, a0, ms[0], ms[1], np.zeros(A, np.float32), np.float32(-np.inf), ocfg)
     np.testing.assert_array_equal(np.sort(pl.elite_idx().cpu().numpy()), np.sort(elite))
     np.testing.assert_allclose(ms1[0], mu, rtol=1e-5, atol=1e-6 * max(1.0, float(np.abs(ub).max())))
-    np.testing.assert_allclose(ms1[1], sigma, rtol=2e-5, atol=1e-6 * max(1.0, float(np.abs(ub).max())))
+    # (a one-point dimension's standard deviation is rounding noise of the order sqrt(k) eps |c|: the mean of k copies of c is not c)
+    np.testing.assert_allclose(ms1[1], sigma, rtol=2e-5, atol=1e-6 * max(1.0, float(np.abs(ub).max())) + 4 * 1.2e-7 * float(np.abs(mu).max()) * np.sqrt(k))
     pl.plan_rollout(1)
     torch.cuda.synchronize()
     a1 = pl.actions().cpu().numpy().copy()

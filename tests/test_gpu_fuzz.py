@@ -168,7 +168,10 @@ def test_random_shape_whole_plan_teacher_forced(seed):
         got = pl.mu_sigma().cpu().numpy().copy()
         amag = max(1.0, float(np.abs(ub).max()))             # mu / sigma live on the scale of the Box (+-100 when it is unbounded)
         np.testing.assert_allclose(got[0], mu, rtol=1e-5, atol=1e-6 * amag, err_msg=str((c, it)))
-        np.testing.assert_allclose(got[1], sigma, rtol=2e-5, atol=1e-6 * amag, err_msg=str((c, it)))
+        # a dimension whose samples are all the same value c (a one-point Box dimension: sigma0 = 0) has a standard deviation of pure
+        # rounding noise — the mean of k copies of c is not c — of the order sqrt(k) eps |c| in either summation order (60x hunt, round 4)
+        sig_atol = 1e-6 * amag + 4 * 1.2e-7 * float(np.abs(mu).max()) * np.sqrt(k)
+        np.testing.assert_allclose(got[1], sigma, rtol=2e-5, atol=sig_atol, err_msg=str((c, it)))
         ms = got                                        # teacher forcing: the next iteration samples from the GPU's own refit
         # the stop rule compares mean(sigma) with the threshold: only decisive margins are asserted
         margin = abs(float(sigma.mean()) - c['thr'])
