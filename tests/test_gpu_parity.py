@@ -592,6 +592,42 @@ def test_early_stop_and_call_counter():
     np.testing.assert_array_equal(a, c)          # and (seed, call) reproduces
 
 
+@pytest.mark.parametrize('variant', ['cem', 'safe'])
+def test_early_stop_under_graph_replay_hands_over_the_stopping_iterations_result(variant):
+    """`mean(sigma) <= stddev_threshold` (cem_mpc.py:66-67) inside a captured plan: the iterations after the stop still launch and return
+    at once, and the RESULT is the stopping iteration's — on single-rank CemMpc plans it is that iteration's select which hands the
+    checksummed block to the polling host while the trailing nodes are still draining; SafeCemMpc goes through the final kernel.  Plans
+    launched back to back on the replayed graph (stopping after 1, some and all iterations) equal the eager planner's bit for bit."""
+    torch = _torch()
+    pb = hp.make_problem(seed=72)
+    N, H, P, E, k, I = 192, 6, 5, 5, 19, 6
+
+    def planner(thr, graph):
+        _, cfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, variant=variant, thr=thr, noise=0.02, post=0.3, use_graph=graph)
+        return hp.make_planner(pb, cfg)
+    # sigma after each refit of the unstopped plan tells which thresholds stop where
+    probe = planner(-1.0, False)
+    probe.plan_begin(pb['state'], seed=4, call=0)
+    sig = []
+    for it in range(I):
+        probe.plan_rollout(it); probe.plan_select(it)
+        torch.cuda.synchronize()
+        sig.append(float(probe.mu_sigma()[1].mean().item()))
+    probe.plan_end(); probe.close()
+    assert all(a > b for a, b in zip(sig, sig[1:])), sig                    # the distribution contracts: thresholds between them stop in between
+    for stop_after in (1, 3, I):
+        thr = 10.0 if stop_after == 1 else (0.5 * (sig[stop_after - 2] + sig[stop_after - 1]) if stop_after < I else -1.0)
+        pe, pg = planner(thr, False), planner(thr, True)
+        for call in range(4):                                               # call 0 captures, 1.. replay; no pause between them
+            ae, se, ie = pe.plan(pb['state'], seed=4, call=call)
+            ag, sg, ig = pg.plan(pb['state'], seed=4, call=call)
+            assert ie == ig and (call > 0 or ie == stop_after), (variant, stop_after, call, ie, ig)
+            np.testing.assert_array_equal(ag, ae)
+            assert sg == se
+        assert pg.graph_status() == 'graph'
+        pe.close(); pg.close()
+
+
 def test_residency_table_matches_the_runtime():
     """The tile-size choice (cem_capi.hip auto_chunks) prices co-resident workgroups; its static residency table (used by
     the GPU-less host helper) must be what the runtime reports for the compiled kernels."""
