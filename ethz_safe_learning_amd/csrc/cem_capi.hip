@@ -65,7 +65,7 @@ int validate(const cem_config_t *c)
         c->n_elite < 1 || c->n_elite > c->n_samples || c->world_size < 1 || c->rank < 0 || c->rank >= c->world_size)
         return CEM_ERR_INVALID_ARG;
     if (c->units < 1) return CEM_ERR_INVALID_ARG;
-    if (c->activation < CEM_ACT_RELU || c->activation > CEM_ACT_SOFTPLUS) return CEM_ERR_INVALID_ARG;
+    if (c->activation < CEM_ACT_RELU || c->activation > CEM_ACT_SELU) return CEM_ERR_INVALID_ARG;
     if (!(fabs((double)c->one_minus_smoothing - (1.0 - (double)c->smoothing)) <= 2e-7)) return CEM_ERR_INVALID_ARG;   // see cem_mpc.h
     if (c->units > CEM_WIDE_U) return CEM_ERR_UNSUPPORTED;  // <= 128: the fast kernel (narrower layers run zero-padded, exactly); 129..256: cem_rollout_wide.h
     if (c->obs_dim + c->act_dim > CEM_U) return CEM_ERR_UNSUPPORTED;
@@ -1628,7 +1628,7 @@ int validate_train(const cem_train_config_t *c)
 {
     if (!c || c->abi_version != CEM_ABI_VERSION) return CEM_ERR_INVALID_ARG;
     if (c->inputs_dim < 1 || c->outputs_dim < 1 || c->n_layers < 1 || c->ensemble_size < 1 || c->batch_size < 1) return CEM_ERR_INVALID_ARG;
-    if (c->units < 1 || c->activation < CEM_ACT_RELU || c->activation > CEM_ACT_SOFTPLUS) return CEM_ERR_INVALID_ARG;
+    if (c->units < 1 || c->activation < CEM_ACT_RELU || c->activation > CEM_ACT_SELU) return CEM_ERR_INVALID_ARG;
     if (!(c->dropout_rate >= 0.f && c->dropout_rate < 1.f)) return CEM_ERR_INVALID_ARG;
     if (c->units > CEM_TWIDE || c->inputs_dim > CEM_U || c->outputs_dim > CEM_U || c->batch_size > CEM_TB) return CEM_ERR_UNSUPPORTED;
     return CEM_OK;

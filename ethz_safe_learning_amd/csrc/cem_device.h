@@ -243,7 +243,7 @@ __device__ __forceinline__ float cem_softplus(float x)
 // paths (cem_rollout_wide_kernel, cem_train_step_kernel) — the tuned kernels are relu only.  tanh / exp / expm1 are the device
 // library's (1-2 ulp).  The derivative is written as a function of the layer's OUTPUT h = f(z), which is what the backward pass
 // holds (TensorFlow's own EluGrad / SoftplusGrad / ReluGrad use the same forms): relu [h > 0], tanh 1 - h^2, sigmoid h (1 - h),
-// elu h + 1 below zero, leaky_relu 0.2 at and below zero, softplus sigma(z) = 1 - exp(-h).
+// elu h + 1 below zero, leaky_relu 0.2 at and below zero, softplus sigma(z) = 1 - exp(-h), selu h + scale alpha below zero and scale above.
 __device__ __forceinline__ float cem_activation_fwd(const int a, const float v)
 {
     switch (a) {
@@ -252,6 +252,7 @@ __device__ __forceinline__ float cem_activation_fwd(const int a, const float v)
     case 3: return v > 0.f ? v : expm1f(v);
     case 4: return v > 0.f ? v : 0.2f * v;
     case 5: return cem_softplus(v);
+    case 6: return v > 0.f ? 1.0507009873554805f * v : 1.7580993408473766f * expm1f(v);     // tf.nn.selu: scale * (z or alpha * (e^z - 1)); scale * alpha = 1.7580993
     default: return fmaxf(v, 0.f);
     }
 }
@@ -263,6 +264,7 @@ __device__ __forceinline__ float cem_activation_gate(const int a, const float d,
     case 3: return h < 0.f ? d * (h + 1.0f) : d;
     case 4: return h > 0.f ? d : 0.2f * d;
     case 5: return d * (1.0f - expf(-h));
+    case 6: return h < 0.f ? d * (h + 1.7580993408473766f) : d * 1.0507009873554805f;       // TensorFlow's SeluGrad, on the layer's output
     default: return h > 0.f ? d : 0.f;
     }
 }

@@ -60,8 +60,9 @@ enum cem_variant { CEM_VARIANT_CEM = 0 /* CemMpc */, CEM_VARIANT_SAFE = 1 /* Saf
 
 /* mlp_params['activation'] of config/models.yaml:12, which the reference `eval`s (mlp_ensemble.py:14): the hidden layers'
  * nonlinearity.  relu (the shipped value) runs on the tuned kernels; the others on the generic rollout kernel and the
- * GEMM-by-GEMM trainer.  tf.nn.elu: alpha 1; tf.nn.leaky_relu: alpha 0.2 (TensorFlow's defaults). */
-enum cem_activation { CEM_ACT_RELU = 0, CEM_ACT_TANH = 1, CEM_ACT_SIGMOID = 2, CEM_ACT_ELU = 3, CEM_ACT_LEAKY_RELU = 4, CEM_ACT_SOFTPLUS = 5 };
+ * GEMM-by-GEMM trainer.  tf.nn.elu: alpha 1; tf.nn.leaky_relu: alpha 0.2; tf.nn.selu: scale 1.0507..., alpha 1.6732... (TensorFlow's
+ * defaults).  All of these have derivatives that are functions of the layer's OUTPUT, which is what the trainer keeps; swish / gelu do not. */
+enum cem_activation { CEM_ACT_RELU = 0, CEM_ACT_TANH = 1, CEM_ACT_SIGMOID = 2, CEM_ACT_ELU = 3, CEM_ACT_LEAKY_RELU = 4, CEM_ACT_SOFTPLUS = 5, CEM_ACT_SELU = 6 };
 
 /* SafetyGymStateScorer fields used by the 'goal' task (safety_gym.py:104-176).
  * The constants come from safety_gym's Engine config (absent from the

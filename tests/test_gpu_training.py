@@ -173,7 +173,7 @@ def test_validation_loss_over_many_chunks(kernel, monkeypatch):
     tr.close()
 
 
-@pytest.mark.parametrize('activation', ['tf.nn.tanh', 'tf.nn.sigmoid', 'tf.nn.elu', 'tf.nn.leaky_relu', 'tf.nn.softplus'])
+@pytest.mark.parametrize('activation', ['tf.nn.tanh', 'tf.nn.sigmoid', 'tf.nn.elu', 'tf.nn.leaky_relu', 'tf.nn.softplus', 'tf.nn.selu'])
 @pytest.mark.parametrize('E,D,O,L,bt,units', [(2, 62, 60, 3, 64, 128), (2, 20, 17, 2, 37, 48)])
 def test_training_steps_with_other_activations(E, D, O, L, bt, units, activation):
     """mlp_params['activation'] other than relu (the reference evals any string, mlp_ensemble.py:14): the GEMM-by-GEMM trainer with

@@ -28,7 +28,12 @@ def test_activations_follow_tensorflow_definitions():
             'tf.nn.sigmoid': (1 / (1 + np.exp(-z)), np.exp(-z) / (1 + np.exp(-z)) ** 2),
             'tf.nn.elu': ([np.exp(-2.0) - 1, np.exp(-0.5) - 1, 0, 0.5, 2.0], [np.exp(-2.0), np.exp(-0.5), 1, 1, 1]),
             'tf.nn.leaky_relu': ([-0.4, -0.1, 0, 0.5, 2.0], [0.2, 0.2, 0.2, 1, 1]),
-            'tf.nn.softplus': (np.log1p(np.exp(z)), 1 / (1 + np.exp(-z)))}
+            'tf.nn.softplus': (np.log1p(np.exp(z)), 1 / (1 + np.exp(-z))),
+            # selu(z) = 1.0507009873554805 * (z, or 1.6732632423543772 * (e^z - 1) below zero); selu'(0) = scale (TensorFlow's SeluGrad tests out < 0)
+            'tf.nn.selu': ([1.0507009873554805 * 1.6732632423543772 * (np.exp(-2.0) - 1), 1.0507009873554805 * 1.6732632423543772 * (np.exp(-0.5) - 1), 0,
+                            1.0507009873554805 * 0.5, 1.0507009873554805 * 2.0],
+                           [1.0507009873554805 * 1.6732632423543772 * np.exp(-2.0), 1.0507009873554805 * 1.6732632423543772 * np.exp(-0.5),
+                            1.0507009873554805, 1.0507009873554805, 1.0507009873554805])}
     for name, (fv, dv) in want.items():
         f, df = o.activation_and_grad(name)
         np.testing.assert_allclose(f(z), fv, rtol=1e-12, atol=1e-15, err_msg=name)
