@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1244,8 +1245,8 @@ void stage_ctrl(cem_planner *h, const float *state, uint64_t seed, uint64_t call
 
 // The plan is queued: wait for its result.  The kernel that completes it stores the plan counter into pinned host memory after
 // everything else of the result, so the host watches that word — a few hundred nanoseconds after the store — instead of going
-// through hipStreamSynchronize (an interrupt / yield path that took ~10 us of a 1.9-ms plan).  Bounded: after ~50 ms of polling (a
-// plan that long is not latency-critical; a faulted device never writes the word) the ordinary synchronisation takes over.
+// through hipStreamSynchronize (an interrupt / yield path that took ~10 us of a 1.9-ms plan).  Bounded: after 100 ms of polling the
+// ordinary synchronisation takes over.
 // the block is complete when it carries this plan's counter AND its checksum holds (device -> host writes arrive in no particular order)
 bool result_landed(const cem_planner *h)
 {
@@ -1258,11 +1259,17 @@ bool result_landed(const cem_planner *h)
 
 int wait_result(cem_planner *h)
 {
-    for (long spin = 0; spin < 20000000l; ++spin) {
-        if (result_landed(h)) { std::atomic_thread_fence(std::memory_order_acquire); return CEM_OK; }
+    // CEM_NO_POLL: a host that would rather sleep than spin a core for the ~2 ms of a plan goes straight to the stream synchronisation
+    static const bool no_poll = std::getenv("CEM_NO_POLL") != nullptr;
+    if (!no_poll) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spin = 1;; ++spin) {
+            if (result_landed(h)) { std::atomic_thread_fence(std::memory_order_acquire); return CEM_OK; }
 #if defined(__x86_64__)
-        __builtin_ia32_pause();
+            __builtin_ia32_pause();
 #endif
+            if ((spin & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(100)) break;   // a plan that long is not latency-critical; a faulted device never writes the block
+        }
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     return CEM_OK;

@@ -26,6 +26,8 @@
  *                                  tile plan, see cem_planner_launches_per_iteration).
  *   CEM_ASSUME_CUS=<n>             price tile plans for n compute units (the GPU-less host helpers default to 256; on a device it
  *                                  overrides multiProcessorCount).
+ *   CEM_NO_POLL                    cem_planner_plan waits for a captured plan with hipStreamSynchronize instead of polling the result block in
+ *                                  pinned memory (polling spins one host core for the duration of the plan and returns ~10 us sooner).
  *   CEM_FORCE_GENERIC_ROLLOUT      every configuration on the width-generic rollout kernel;  CEM_TRAIN_GEMM_KERNEL: the GEMM-by-GEMM trainer.
  */
 #ifndef CEM_MPC_H

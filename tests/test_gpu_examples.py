@@ -60,3 +60,26 @@ except Exception as e:
     n_runtimes = r.stderr.count('libamdhip64')
     if 'create failed' in r.stdout or n_runtimes:
         assert 'HIP runtimes are loaded in this process' in r.stderr, r.stderr[-2000:]
+
+
+def test_polling_and_synchronising_hosts_get_the_same_plan():
+    """cem_planner_plan on a captured graph waits for the result block by polling pinned memory; CEM_NO_POLL=1 (read once per process)
+    makes it synchronise the stream instead.  Same plans either way."""
+    import subprocess
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+from tests import helpers as hp
+pb = hp.make_problem(seed=9)
+_, cfg = hp.configs(pb, N=160, H=6, P=5, E=5, k=16, I=3, noise=0.02, use_graph=True)
+pl = hp.make_planner(pb, cfg)
+out = [pl.plan(pb['state'], seed=2, call=c) for c in range(4)]
+assert pl.graph_status() == 'graph'
+print('RESULT', [(a.tolist(), s, it) for a, s, it in out])
+''' % ROOT
+    res = {}
+    for tag, env in (('poll', {}), ('sync', {'CEM_NO_POLL': '1'})):
+        r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = [ln for ln in r.stdout.splitlines() if ln.startswith('RESULT')][0]
+    assert res['poll'] == res['sync']
