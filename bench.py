@@ -333,14 +333,15 @@ def b5_leg(torch, dist, pb, G, rank, dev, native, steps, warmup, rehearse_world=
         return {'error': 'skipped on every rank: set-up failed on %s' % ('this rank: ' + setup_error if setup_error else 'another rank')}
     if rehearse_world:
         exchange = 'rehearsal: device copy of this rank\'s shard (1 process playing rank 0 of %d)' % W
-        pl.scores_global().copy_(torch.from_numpy(np.random.default_rng(0).standard_normal(N).astype(np.float32)))
         lo, hi = 0, N // W
+        frames = synthetic.rehearsal_score_frames(pl, pb['state'], W, I, seed=2028)     # the other ranks' shards: shaped like this rank's own
 
         def one_plan(i):
             pl.plan_begin(pb['state'], seed=2028, call=i)
             for it in range(I):
                 pl.plan_rollout(it)
                 with torch.cuda.stream(pl.stream):
+                    pl.scores_global()[hi:].copy_(frames[it, hi:])
                     pl.scores_global()[lo:hi].copy_(pl.scores_local())
                 pl.plan_select(it)
             return pl.plan_end()

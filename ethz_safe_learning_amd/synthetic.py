@@ -48,3 +48,29 @@ def problem(obs_dim=60, act_dim=2, ensemble_size=5, units=128, n_layers=4, seed=
 def flops_per_row_step(obs_dim, act_dim, units=128, n_layers=4):
     """2*[(O+A)*U + (L-1)*U^2 + 2*U*O]  (SURVEY.md section 8d)."""
     return 2 * ((obs_dim + act_dim) * units + (n_layers - 1) * units * units + 2 * units * obs_dim)
+
+
+def rehearsal_score_frames(planner, state, world, iterations, seed=0, call=0):
+    """Stand-ins for the OTHER ranks' score shards when one process plays one rank of `world` on a single GPU (bench.py's B5 rehearsal,
+    scripts/time_b5_rank.py): I frames of N floats, frame i = this rank's own scores of iteration i (from one stepwise plan in which
+    the foreign slots hold the previous frame), tiled over the world and jittered by 1 % so that no two candidates tie.  The select's
+    cost depends on how the scores are distributed (a bucket that holds the k-th key and hundreds of others takes refinement passes);
+    in a real run every rank's candidates come from the same mean / stddev, so the foreign slots have to look like the rank's own —
+    uncorrelated filler (standard normals next to objective sums) triples the select time at N = 65536 and is not what a node would see."""
+    import torch
+    N, nloc = planner.cfg.n_samples, planner.n_local
+    g = torch.Generator(device='cpu'); g.manual_seed(1234 + seed)
+    jitter = (1.0 + 0.01 * torch.randn(world, nloc, generator=g)).to(planner.scores_global().device)
+    frames = torch.empty(iterations, N, dtype=torch.float32, device=jitter.device)
+    planner.plan_begin(state, seed=seed, call=call)
+    for it in range(iterations):
+        planner.plan_rollout(it)
+        with torch.cuda.stream(planner.stream):
+            own = planner.scores_local().clone()
+            frames[it] = (own.unsqueeze(0) * jitter).reshape(N)
+            planner.scores_global().copy_(frames[it])
+            planner.scores_global()[planner.cfg.rank * nloc:(planner.cfg.rank + 1) * nloc].copy_(own)
+        planner.plan_select(it)
+    planner.plan_end()
+    torch.cuda.synchronize()
+    return frames

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """What ONE rank of a candidate-sharded plan pays, measured on one GPU (no collective: the all-gather is replaced by a
-device copy of this rank's shard into the global score vector, the other shards keep the previous values).
+two device copies per iteration: this rank's shard and stand-ins for the other ranks' shards shaped like its own —
+synthetic.rehearsal_score_frames).
 
   B5       N = 65536 over 8 ranks (8192 candidates per rank), K = P = E = 5, H = 30, k = 6554   (BASELINE.json configs[4])
   weak8    N = 16000 over 8 ranks (2000 per rank): bench.py --gpus 8
@@ -30,8 +31,8 @@ def run(name, N, world, rank=0):
     pl.set_weights(pb['weights'])
     pl.set_normaliser(pb['inputs_min'], pb['inputs_max'])
     st = pl.stream
-    if world > 1:       # something plausible in the other ranks' score slots
-        pl.scores_global().copy_(torch.from_numpy(np.random.default_rng(0).standard_normal(N).astype(np.float32)))
+    nloc = N // world
+    frames = synthetic.rehearsal_score_frames(pl, pb['state'], world, I, seed=11) if world > 1 else None   # the other ranks' shards, shaped like this one's
     torch.cuda.synchronize()
     t_roll, t_sel, t_plan = [], [], []
     for rep in range(reps + 2):
@@ -43,7 +44,8 @@ def run(name, N, world, rank=0):
             ev[1 + 2 * it].record(st)
             if world > 1:
                 with torch.cuda.stream(st):
-                    pl.scores_global()[rank * (N // world):(rank + 1) * (N // world)].copy_(pl.scores_local())
+                    pl.scores_global()[nloc:].copy_(frames[it, nloc:])
+                    pl.scores_global()[:nloc].copy_(pl.scores_local())
             pl.plan_select(it)
             ev[2 + 2 * it].record(st)
         pl.plan_end()
@@ -59,6 +61,10 @@ def run(name, N, world, rank=0):
         pl.plan_begin(pb['state'], seed=12, call=rep)
         for it in range(I):
             pl.plan_rollout(it)
+            if world > 1:
+                with torch.cuda.stream(st):
+                    pl.scores_global()[nloc:].copy_(frames[it, nloc:])
+                    pl.scores_global()[:nloc].copy_(pl.scores_local())
             pl.plan_select(it)
         pl.plan_end()
         tm = pl.last_timing()
