@@ -8,7 +8,11 @@ sample -> rollout+score -> select/refit, early stop disabled so exactly I iterat
 
 Workload: BASELINE config B2 (obs=60, act=2, K=P=E=5, N=2000, H=30, I=5, k=N/10) at N=1.  At G>1 the candidate
 count is weak-scaled (N = 2000*G, every rank rolls out 2000 candidates x 5 particles) and `value` is in
-B2-equivalent plans/s = candidate-trajectory-steps/s / 300000, so it equals plain plans/s at G=1.
+B2-equivalent plans/s = candidate-trajectory-steps/s / 300000, so it equals plain plans/s at G=1.  The same line carries the
+unscaled rate (`weak_plans_per_s`) and, as labelled extras, the literal metric strong-scaled (`b2_strong`: N = 2000 in total, 2000/G per
+rank, plain plans/s) and BASELINE config 5 (`b5`: N = 65536 over the G ranks).  A single-GPU run adds `configs`: B1 / B3 / B4 whole plans,
+one rank of B5's eight, and the reference's own policies — SafeCemMpc at the headline shape (`B2_safe`) and the shapes it ships
+(`shipped_safe_cem_mpc`, `shipped_cem_mpc`, each with early stop off and as shipped).
 """
 import argparse
 import json
@@ -223,24 +227,32 @@ def all_ranks_ok(torch, dist, ok, ctl_dev):
 class HeadlineGuard:
     """The extra legs of a multi-rank run (B5, its split-product form) contain collectives.  If a rank dies or faults INSIDE one, the
     others block in it and nothing in-process can agree about anything any more — so before the extras start, every rank arms a
-    timer: if the extras have not finished within `seconds`, rank 0 prints the line it already has (headline complete, the extras
-    marked as timed out) and every rank leaves with os._exit, so the launcher sees an orderly end instead of its own timeout and the
-    run keeps its headline."""
+    timer: if the extras have not finished within `seconds`, rank 0 prints the line it already has (headline complete, top-level
+    `extras_timed_out: true`, the extras marked as timed out), every rank writes a line to stderr and leaves with os._exit, so the
+    launcher sees an end instead of its own timeout and the run keeps its headline.  The exit status is `--extras-timeout-status`
+    (default 0: a launcher that discards the stdout of a failed run would lose the headline the guard exists to keep; the flag and the
+    stderr lines mark the run as one to investigate either way)."""
 
-    def __init__(self, out, rank, seconds):
+    def __init__(self, out, rank, seconds, exit_code=0):
         import threading
-        self.out, self.rank = out, rank
+        self.out, self.rank, self.exit_code = out, rank, exit_code
         self.timer = threading.Timer(seconds + (0.0 if rank == 0 else 5.0), self.fire)
         self.timer.daemon = True
         self.seconds = seconds
 
     def fire(self):
+        # never silent: the cause of the hang has to be looked for in this run's records, so every rank says so on stderr and the line
+        # carries a TOP-LEVEL flag (not only an error string nested in the extras)
+        sys.stderr.write('bench.py rank %d: the multi-rank extras did not finish within %d s (a rank blocked in a collective, or a GPU hang): '
+                         'printing the headline as it stands with "extras_timed_out": true and leaving with status %d\n' % (self.rank, self.seconds, self.exit_code))
+        sys.stderr.flush()
         if self.rank == 0:
             line = dict(self.out)
-            for key in ('b5', 'b5_split_bf16x3'):
+            line['extras_timed_out'] = True
+            for key in ('b2_strong', 'b5', 'b5_split_bf16x3'):
                 line.setdefault(key, {'error': 'did not finish within %d s (a rank blocked in a collective?); headline printed by the guard' % self.seconds})
             print(json.dumps(line), flush=True)
-        os._exit(0)
+        os._exit(self.exit_code)
 
     def __enter__(self):
         self.timer.start()
@@ -251,61 +263,103 @@ class HeadlineGuard:
         return False
 
 
-def config_leg(torch, name, obs, act, K, N, H, dev, steps, warmup):
-    """One more BASELINE config on the same line as the headline (configs[0], [2], [3] of BASELINE.json; [4] is b5_leg): whole plans
-    timed like the headline (graph replay), then the rollout launch by HIP events on the planner's stream.  Labelled extras —
-    `value` stays B2."""
+def config_leg(torch, name, obs, act, K, N, H, dev, steps, warmup, P=None, I=5, k=None, variant='cem', thr=-1.0, post=0.15, noise=1e-3, what=None):
+    """One more configuration on the same line as the headline: whole plans timed like the headline (graph replay), then the launches
+    of an iteration by HIP events on the planner's stream.  Labelled extras — `value` stays B2.  The BASELINE configs (configs[0], [2],
+    [3] of BASELINE.json; [4] is b5_leg) use K = P = E, I = 5, k = N/10, the CemMpc objective and no early stop; the policy legs pass the
+    reference's own ctor values (config/policies.yaml:2-20, config/models.yaml:3): E = K members, P particles, I, k, the variant, the
+    early-stop threshold and the Beta threshold.  `rollout_share_of_plan` = the rollout launches' device time / the plan's wall time;
+    `reduce_us_per_iteration` / `select_us_per_iteration` / `sampler_us_per_iteration`: the other launches of an iteration (0 where a
+    launch does not exist: the reduce is folded into the select on single-rank CemMpc plans, the sampler into the rollout tiles)."""
     from ethz_safe_learning_amd import CemPlanner, PlannerConfig, synthetic
-    I = 5
+    P = K if P is None else P
+    k = N // 10 if k is None else k
     pb = synthetic.problem(obs, act, K)
-    cfg = PlannerConfig(obs_dim=obs, act_dim=act, ensemble_size=K, particles=K, n_samples=N, horizon=H, n_elite=N // 10, iterations=I,
-                        scorer=pb['scorer'], act_low=pb['low'], act_high=pb['high'], stddev_threshold=-1.0, noise_stddev=1e-3, variant='cem',
-                        use_graph=True)
+    cfg = PlannerConfig(obs_dim=obs, act_dim=act, ensemble_size=K, particles=P, n_samples=N, horizon=H, n_elite=k, iterations=I,
+                        scorer=pb['scorer'], act_low=pb['low'], act_high=pb['high'], stddev_threshold=thr, noise_stddev=noise, variant=variant,
+                        posterior_mean_threashold=post, use_graph=True)
     pl = CemPlanner(cfg, device=dev)
     pl.set_weights(pb['weights'])
     pl.set_normaliser(pb['inputs_min'], pb['inputs_max'])
     for i in range(warmup):
         pl.plan(pb['state'], seed=2029, call=i)
     torch.cuda.synchronize()
+    iters_run = []
     t0 = time.perf_counter()
     for i in range(steps):
         a, s, it = pl.plan(pb['state'], seed=2029, call=warmup + i)
+        iters_run.append(it)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    assert it == I and np.all(np.isfinite(a))
+    assert (it == I or thr > 0) and np.all(np.isfinite(a))
     graph = pl.graph_status() == 'graph'
     pl.set_timing(True)
-    roll_ms, sel_ms, roll_n = 0.0, 0.0, 0
+    roll_ms, sel_ms, red_ms, samp_ms, roll_n = 0.0, 0.0, 0.0, 0.0, 0
     for i in range(3):
-        pl.plan(pb['state'], seed=2030, call=i)
+        pl.plan(pb['state'], seed=2029, call=warmup + i)            # (plans timed above: the same iteration counts under early stop)
         tm = pl.last_timing()
-        roll_ms += tm['rollout_ms']; sel_ms += tm['select_ms']; roll_n += tm['rollout_launches']
+        roll_ms += tm['rollout_ms']; sel_ms += tm['select_ms']; red_ms += tm['reduce_ms']; samp_ms += tm['sampler_ms']; roll_n += tm['rollout_launches']
     pl.set_timing(False)
     avg_ms = roll_ms / max(roll_n, 1)
-    flops_launch = synthetic.flops_per_row_step(obs, act) * K * N * H
-    out = dict(workload='%s: obs=%d act=%d K=P=E=%d N=%d H=%d I=5 k=N/10 units=128 layers=4, CemMpc objective, early stop off' % (name, obs, act, K, N, H),
-               plans_per_s=steps / dt, ms_per_plan=1e3 * dt / steps, steps=steps, warmup=warmup,
-               candidate_trajectory_steps_per_s=steps / dt * I * N * H,
+    mean_iters = float(np.mean(iters_run))
+    flops_launch = synthetic.flops_per_row_step(obs, act) * P * N * H
+    label = what or ('%s: obs=%d act=%d K=P=E=%d N=%d H=%d I=%d k=%d units=128 layers=4, %s objective, early stop %s'
+                     % (name, obs, act, K, N, H, I, k, 'SafeCemMpc' if variant == 'safe' else 'CemMpc', 'off' if thr <= 0 else 'at mean(sigma) <= %g' % thr))
+    out = dict(workload=label,
+               plans_per_s=steps / dt, ms_per_plan=1e3 * dt / steps, steps=steps, warmup=warmup, iterations_run_mean=mean_iters,
+               candidate_trajectory_steps_per_s=steps / dt * mean_iters * N * H,
                rollout_ms_per_launch=avg_ms, rollout_launches_timed=roll_n, algorithmic_flops_per_launch=flops_launch,
                rollout_tflops=flops_launch / (avg_ms * 1e-3) / 1e12,
                frac_of_fp32_mfma_peak=flops_launch / (avg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-               plan_frac_of_fp32_mfma_peak=I * flops_launch / (dt / steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-               select_us_per_iteration=1e3 * sel_ms / max(roll_n, 1),
+               plan_frac_of_fp32_mfma_peak=mean_iters * flops_launch / (dt / steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+               rollout_share_of_plan=mean_iters * avg_ms / (1e3 * dt / steps),
+               select_us_per_iteration=1e3 * sel_ms / max(roll_n, 1), reduce_us_per_iteration=1e3 * red_ms / max(roll_n, 1),
+               sampler_us_per_iteration=1e3 * samp_ms / max(roll_n, 1),
                kernel=rollout_kernel_name(pl, obs, act), chunks_per_tile=pl.tiles()[0], tiles=int(len(pl.tiles()[1])),
-               horizon_segments=pl.segments()[0], launches_per_iteration=pl.launches_per_iteration(), hip_graph=graph)
+               horizon_segments=pl.segments()[0], launches_per_iteration=pl.launches_per_iteration(), select_mode=pl.select_mode(), hip_graph=graph)
     pl.close()
     return out
 
 
-def b5_leg(torch, dist, pb, G, rank, dev, native, steps, warmup, rehearse_world=0, ctl_dev=None, precision='fp32'):
+# The reference's own policies at the shapes it ships (config/policies.yaml:2-20 with config/models.yaml:3 `ensemble_size: 15`; the default
+# agent runs safe_cem_mpc, config/agents.yaml:11) and the headline configuration on the SafeCemMpc objective.  Synthetic PointGoal1-shaped
+# observations (obs 60, act 2).  B2_safe keeps the Beta threshold the parity tests use at P = 5 (0.3: with the shipped 0.15 no candidate of
+# five particles can be safe — (alpha + 0) / (alpha + beta + 5) = 0.163 — which costs the same time but scores every candidate -100).
+POLICY_LEGS = (
+    # name, K (= E), P, N, H, I, k, variant, thr, post, noise, steps, warmup
+    ('B2_safe', 5, 5, 2000, 30, 5, 80, 'safe', -1.0, 0.3, 1e-3, 40, 10),
+    ('shipped_safe_cem_mpc', 15, 45, 500, 8, 9, 20, 'safe', -1.0, 0.15, 0.01, 40, 10),
+    ('shipped_safe_cem_mpc_early_stop', 15, 45, 500, 8, 9, 20, 'safe', 0.25, 0.15, 0.01, 40, 10),
+    ('shipped_cem_mpc', 15, 5, 150, 8, 10, 15, 'cem', -1.0, 0.15, 0.001, 100, 20),
+    ('shipped_cem_mpc_early_stop', 15, 5, 150, 8, 10, 15, 'cem', 0.25, 0.15, 0.001, 100, 20),
+)
+
+
+def policy_legs(torch, dev):
+    legs = {}
+    for name, K, P, N, H, I, k, variant, thr, post, noise, st_, wu_ in POLICY_LEGS:
+        what = ('%s: obs=60 act=2 ensemble_size=%d particles=%d n_samples=%d horizon=%d iterations=%d n_elite=%d units=128 layers=4, %s, '
+                'stddev_threshold %s, noise_stddev %g' % (name, K, P, N, H, I, k, 'SafeCemMpc (posterior_mean_threashold %g)' % post if variant == 'safe' else 'CemMpc',
+                                                          'off (every iteration runs)' if thr <= 0 else '%g as shipped' % thr, noise))
+        try:
+            legs[name] = config_leg(torch, name, 60, 2, K, N, H, dev, steps=st_, warmup=wu_, P=P, I=I, k=k, variant=variant, thr=thr, post=post,
+                                    noise=noise, what=what)
+        except Exception as e:
+            legs[name] = {'error': str(e)[:300]}
+    return legs
+
+
+def b5_leg(torch, dist, pb, G, rank, dev, native, steps, warmup, rehearse_world=0, ctl_dev=None, precision='fp32', N=65536, k=6554, label='B5'):
     """BASELINE.json configs[4], strong-scaled: N = 65536 candidates (K = P = E = 5, H = 30, I = 5, k = 6554) sharded over the G
     ranks of this run, one all-gather of the scores per CEM iteration.  Timed like the headline: barrier + synchronize on both
     sides, max over ranks.  `rehearse_world` = R > 0 (CEM_BENCH_B5_REHEARSAL=R on a one-GPU box): this process plays rank 0 of R —
     65536/R candidates, the replicated sample and select over all 65536 — with the all-gather replaced by a device copy of its
     own shard (the other ranks' scores keep plausible stale values), as scripts/time_b5_rank.py does; the stepwise C-ABI calls are
-    the ones the host-stepped multi-rank driver makes."""
+    the ones the host-stepped multi-rank driver makes.
+    With N = 2000, k = 200, label 'B2' the same leg is the LITERAL metric of BASELINE.json at G GPUs — "(N=2000 K=5 H=30) at 1/2/4/8":
+    2000 candidates in total, 2000/G per rank, plain plans/s (`b2_strong`; the headline `value` weak-scales instead)."""
     from ethz_safe_learning_amd import CemPlanner, PlannerConfig, synthetic
-    obs, act, K, H, I, N, k = 60, 2, 5, 30, 5, 65536, 6554
+    obs, act, K, H, I = 60, 2, 5, 30, 5
     W = rehearse_world or G
     cfg = PlannerConfig(obs_dim=obs, act_dim=act, ensemble_size=K, particles=K, n_samples=N, horizon=H, n_elite=k, iterations=I,
                         scorer=pb['scorer'], act_low=pb['low'], act_high=pb['high'], stddev_threshold=-1.0, noise_stddev=1e-3, variant='cem',
@@ -341,8 +395,8 @@ def b5_leg(torch, dist, pb, G, rank, dev, native, steps, warmup, rehearse_world=
             for it in range(I):
                 pl.plan_rollout(it)
                 with torch.cuda.stream(pl.stream):
-                    pl.scores_global()[hi:].copy_(frames[it, hi:])
-                    pl.scores_global()[lo:hi].copy_(pl.scores_local())
+                    pl.scores_global(sync=False)[hi:].copy_(frames[it, hi:])
+                    pl.scores_global(sync=False)[lo:hi].copy_(pl.scores_local(sync=False))
                 pl.plan_select(it)
             return pl.plan_end()
     elif native:
@@ -383,7 +437,7 @@ def b5_leg(torch, dist, pb, G, rank, dev, native, steps, warmup, rehearse_world=
     pl.set_timing(False)
     flops_launch = synthetic.flops_per_row_step(obs, act) * K * (N // W) * H
     avg_ms = roll_ms / max(roll_n, 1)
-    out = dict(workload='B5: obs=60 act=2 K=P=E=5 N=65536 H=30 I=5 k=6554, strong-scaled over %d ranks' % W, scaling='strong',
+    out = dict(workload='%s: obs=60 act=2 K=P=E=5 N=%d H=30 I=5 k=%d, strong-scaled over %d ranks' % (label, N, k, W), scaling='strong', unit='plans/s',
                plans_per_s=steps / dt, ms_per_plan=1e3 * dt / steps, steps=steps, n_ranks=W, candidates_per_rank=N // W,
                candidate_trajectory_steps_per_s=steps / dt * I * N * H,
                rollout_ms_per_launch=avg_ms, rollout_frac_of_fp32_mfma_peak_per_rank=flops_launch / (avg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
@@ -407,6 +461,7 @@ def main():
     ap.add_argument('--no-configs', action='store_true', help='skip the B1 / B3 / B4 / B5-rank extras of a single-GPU run')
     ap.add_argument('--no-b5', action='store_true', help='skip the B5 extras of a multi-GPU run')
     ap.add_argument('--extras-timeout', type=int, default=240, help='seconds after which a multi-rank run prints its headline without the extras')
+    ap.add_argument('--extras-timeout-status', type=int, default=0, help='exit status of a run whose extras timed out (the line then carries "extras_timed_out": true)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--chunks', type=int, default=0)
     ap.add_argument('--segments', type=int, default=0, help='rollout work-queue segments: 0 auto, 1 off')
@@ -554,6 +609,8 @@ def main():
                                                                       else 'torch.distributed all_gather between ctypes calls'),
                    'parallelism': 'candidates sharded x%d, 1 all-gather of scores/iter' % G},
         'candidate_trajectory_steps_per_s': plans_per_s * I * N * H,
+        # the same timed interval without the B2-equivalent scaling: whole plans of N = 2000 x G candidates per second
+        'weak_plans_per_s': plans_per_s, 'weak_candidates_per_plan': N,
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic, 'mfma_busy_frac': mfma_util,
                      'hbm_gbps': (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None, 'hbm_peak_gbps': PEAK_HBM_GBPS,
@@ -568,7 +625,10 @@ def main():
             pl.comm_destroy()                          # one communicator at a time
         # an extra must never cost the run its headline: failures a rank can have on its own are agreed on before the leg's first
         # collective (b5_leg), and a leg that blocks is cut off by the guard, which prints the headline as it stands
-        with HeadlineGuard(out, rank, args.extras_timeout):
+        with HeadlineGuard(out, rank, args.extras_timeout, args.extras_timeout_status):
+            if 2000 % (rehearse or G) == 0:            # the literal metric: N = 2000 candidates in total over the ranks, plain plans/s
+                out['b2_strong'] = b5_leg(torch, dist, pb, G, rank, dev, native, steps=min(args.steps, 50), warmup=min(max(args.warmup, 2), 10),
+                                          rehearse_world=rehearse if G == 1 else 0, ctl_dev=ctl_dev, N=2000, k=200, label='B2')
             out['b5'] = b5_leg(torch, dist, pb, G, rank, dev, native, steps=min(args.steps, 20), warmup=min(max(args.warmup, 2), 5),
                                rehearse_world=rehearse if G == 1 else 0, ctl_dev=ctl_dev)
             if not args.no_split_leg:                  # the same sharded plan on the opt-in split-product rollout: a labelled extra, never `value`
@@ -587,6 +647,7 @@ def main():
             legs['B5_rank'] = b5_leg(torch, None, pb, 1, 0, dev, False, steps=10, warmup=3, rehearse_world=8, ctl_dev=ctl_dev)
         except Exception as e:
             legs['B5_rank'] = {'error': str(e)[:300]}
+        legs.update(policy_legs(torch, dev))          # the reference's default policy and shipped shapes, and the headline shape on SafeCemMpc
         out['configs'] = legs
     if G == 1 and not distributed and not args.no_split_leg:
         try:

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     'cem_packed_weight_floats', 'cem_workspace_bytes', 'cem_pack_weights_host', 'cem_plan_tiles_host', 'cem_plan_segments_host', 'cem_rollout_residency',
     'cem_planner_create', 'cem_planner_destroy', 'cem_planner_layout', 'cem_planner_set_weights',
     'cem_planner_set_normaliser', 'cem_planner_plan', 'cem_plan_begin', 'cem_plan_rollout', 'cem_plan_select',
-    'cem_plan_end', 'cem_comm_unique_id', 'cem_planner_comm_init', 'cem_planner_comm_destroy', 'cem_planner_comm_ranks', 'cem_plan_exchange', 'cem_planner_graph_status', 'cem_planner_launches_per_iteration', 'cem_unfold_sequences', 'cem_compute_objective', 'cem_scorer_reward', 'cem_scorer_cost', 'cem_fill_noise', 'cem_philox_words', 'cem_planner_set_timing', 'cem_planner_last_timing',
+    'cem_plan_end', 'cem_comm_unique_id', 'cem_planner_comm_init', 'cem_planner_comm_destroy', 'cem_planner_comm_ranks', 'cem_plan_exchange', 'cem_planner_graph_status', 'cem_planner_launches_per_iteration', 'cem_unfold_sequences', 'cem_compute_objective', 'cem_scorer_reward', 'cem_scorer_cost', 'cem_fill_noise', 'cem_philox_words', 'cem_planner_set_timing', 'cem_planner_last_timing', 'cem_planner_last_timing_detail', 'cem_planner_select_mode', 'cem_planner_inject_fault',
     'cem_trainer_workspace_bytes', 'cem_trainer_blob_floats', 'cem_trainer_create', 'cem_trainer_destroy', 'cem_trainer_set_state',
     'cem_trainer_get_state', 'cem_trainer_step', 'cem_trainer_steps', 'cem_trainer_eval',
 ]
@@ -129,8 +129,11 @@ def load():
     lib.cem_scorer_cost.argtypes = [vp, vp, C.c_int32, vp]
     lib.cem_fill_noise.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, vp]
     lib.cem_philox_words.argtypes = [vp, C.c_uint64, C.c_uint64] + [C.c_uint32] * 6 + [vp]
+    lib.cem_planner_select_mode.argtypes = [vp, i32p]
+    lib.cem_planner_inject_fault.argtypes = [vp, C.c_int32]
     lib.cem_planner_set_timing.argtypes = [vp, C.c_int32]
     lib.cem_planner_last_timing.argtypes = [vp, fp, i32p, fp]
+    lib.cem_planner_last_timing_detail.argtypes = [vp, fp, fp]
     tcfgp = C.POINTER(CemTrainConfig)
     for f in ('cem_trainer_workspace_bytes', 'cem_trainer_blob_floats'):
         getattr(lib, f).restype = C.c_size_t

@@ -328,7 +328,7 @@ int query_resident(bool seg)
 
 // Per-device facts the tile plan is priced with, asked from the runtime once per device (thread-safe: one std::call_once per
 // device slot; the last slot serves a process without a device and holds the static tables).
-struct DeviceFacts { std::once_flag once; int resident[2][2][4]; int cus; };
+struct DeviceFacts { std::once_flag once; int resident[2][2][4]; int cus; int cus_real; };
 static DeviceFacts g_facts[CEM_MAX_DEVICES + 1];
 
 const DeviceFacts &device_facts()
@@ -357,7 +357,10 @@ const DeviceFacts &device_facts()
         else (void)hipGetLastError();
         // The cost model is per CU (tiles on the busiest CU x the cost of a chunk among k co-resident ones): another CU count only
         // changes how many tiles a CU gets, not the table.  CEM_ASSUME_CUS=n prices plans for n CUs (a diagnostic: the GPU-less host
-        // helpers and tests/test_capi_cpu.py use it to see the choice move with the CU count; on a device it overrides the real count).
+        // helpers and tests/test_capi_cpu.py use it to see the choice move with the CU count).  It moves the tile PLAN only: whatever
+        // has to hold on the device that runs the plan — how many workgroups are resident at once (the fused select's grid barriers, where
+        // the sampler runs) — is computed from the real count, cus_real.
+        f.cus_real = f.cus;
         if (const char *e = std::getenv("CEM_ASSUME_CUS")) { const int n = std::atoi(e); if (n >= 1 && n <= 4096) f.cus = n; }
     });
     return f;
@@ -365,7 +368,8 @@ const DeviceFacts &device_facts()
 
 // seg: the pinned + floating-segment launch (cem_rollout_seg_kernel) instead of one workgroup per tile (cem_rollout_kernel)
 int resident_workgroups(int nfw, int rc, bool seg = false) { return device_facts().resident[seg ? 1 : 0][nfw - 1][rc - 1]; }
-int num_cus() { return device_facts().cus; }
+int num_cus() { return device_facts().cus; }            // what tile plans are priced for (CEM_ASSUME_CUS moves it)
+int real_cus() { return device_facts().cus_real; }      // what the device has
 
 // ---- pinned tiles + floating horizon segments ----------------------------------------------------------------------------
 // One workgroup per tile for the whole horizon makes the busiest CU carry ceil(tiles / CUs) tiles while the mean is
@@ -622,8 +626,8 @@ struct cem_planner {
     uint32_t plan_seq;                       // plans staged on this handle (CtrlBlock::seq)
     const CtrlBlock *d_h_ctrl; float *d_h_result;     // the same two blocks as the DEVICE addresses them (hipHostGetDevicePointer)
     // timing
-    bool timing; std::vector<hipEvent_t> ev; float roll_ms, sel_ms; int roll_n;
-    std::vector<std::pair<int, int>> ev_kind;   // (event index of start, kind 0 rollout / 1 select)
+    bool timing; std::vector<hipEvent_t> ev; float roll_ms, sel_ms, red_ms, samp_ms; int roll_n;
+    std::vector<std::pair<int, int>> ev_kind;   // (event index of start, kind 0 rollout / 1 select / 2 reduce / 3 sampler launch)
     // graph
     hipGraph_t graph; hipGraphExec_t gexec; bool graph_ready;
     ScorerDev sc;
@@ -634,6 +638,8 @@ struct cem_planner {
     size_t sel_dyn_limit;                    // dynamic-LDS allowance of the select kernels on this handle's device
     int fused_resident;                      // workgroups of cem_msel_fused_kernel the device keeps resident at once (occupancy x CUs)
     bool sel_zeroed;                         // the multi-workgroup select's histograms / barrier counter were cleared by this iteration's reduce kernel
+    bool fuse_banned;                        // a grid barrier of the fused select expired on this handle once (recovered in-stream): select_mode 2 from then on
+    uint32_t inject_next;                    // cem_planner_inject_fault: CtrlBlock::inject of the next plan
     // grow-only device scratch of the standalone ops (unfold_sequences tiles + returns, compute_objective returns + costs)
     char *scratch; size_t scratch_bytes;
     std::vector<float> h_etab;               // host copy of RolloutParams::etab ([E][CEM_ET_ROWS + L][128]); re-uploaded whole by create / set_weights / set_normaliser
@@ -759,16 +765,16 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
       // tiles are resident at once (one round of prologues per launch: B1, B2) — one launch and one graph node fewer per iteration for
       // about what the launch cost; as a launch of its own when tiles queue for slots (B3: 8 tiles per CU; every round of tiles would
       // pay the prologue on its critical path, and each candidate is sampled once per particle: K = 16 measured +1.5 % on the launch).
-      const int slots = num_cus() * ((h->d.wide || h->d.split) ? 1 : resident_workgroups(h->d.NFW, pl.rc, pl.n_seg > 1));
+      const int slots = real_cus() * ((h->d.wide || h->d.split) ? 1 : resident_workgroups(h->d.NFW, pl.rc, pl.n_seg > 1));
       h->sample_in_rollout = pl.n_tiles <= slots;
       if (const char *e = std::getenv("CEM_FORCE_SAMPLER"))      // diagnostic / tests: "tile" or "kernel" — the results do not depend on it
           h->sample_in_rollout = std::strcmp(e, "kernel") != 0; }
     h->have_weights = false; h->in_plan = false; h->eps_act = h->eps_model = nullptr;
-    h->timing = false; h->roll_ms = h->sel_ms = 0.f; h->roll_n = 0;
+    h->timing = false; h->roll_ms = h->sel_ms = h->red_ms = h->samp_ms = 0.f; h->roll_n = 0;
     h->graph = nullptr; h->gexec = nullptr; h->graph_ready = false;
     h->comm = nullptr; h->plans_since_comm = 0; h->graph_failed = false;
     h->h_ctrl = nullptr; h->h_result = nullptr;
-    h->scratch = nullptr; h->scratch_bytes = 0; h->sel_zeroed = false; h->plan_seq = 0;
+    h->scratch = nullptr; h->scratch_bytes = 0; h->sel_zeroed = false; h->plan_seq = 0; h->fuse_banned = false; h->inject_next = 0;
     // every failure from here on frees what was acquired and reports the HIP code
     auto fail = [&](int status) {
         g_last_hip = (int)hipGetLastError();
@@ -778,8 +784,10 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
         delete h;
         return status;
     };
-    if (hipHostMalloc((void **)&h->h_ctrl, sizeof(CtrlBlock), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void **)&h->h_result, 64 * 4, hipHostMallocDefault) != hipSuccess) return fail(CEM_ERR_HIP);
+    // mapped + coherent (fine-grained) host memory, asked for explicitly: the device reads the staged block and writes the result in place,
+    // and the host polls that result while the stream is still running
+    if (hipHostMalloc((void **)&h->h_ctrl, sizeof(CtrlBlock), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostMalloc((void **)&h->h_result, 64 * 4, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return fail(CEM_ERR_HIP);
     std::memset(h->h_ctrl, 0, sizeof(CtrlBlock));
     std::memset(h->h_result, 0, 64 * 4);
     {   // kernels read the staged control block and write the plan's result in place (no copy nodes around a plan)
@@ -853,7 +861,7 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
     {
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cem_msel_fused_kernel, 1024, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 0; }
-        h->fused_resident = per_cu * num_cus();
+        h->fused_resident = per_cu * real_cus();
     }
     *out = h;
     return CEM_OK;
@@ -862,6 +870,9 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
 int cem_planner_destroy(cem_planner_t *h)
 {
     if (!h) return CEM_ERR_INVALID_ARG;
+    // a polled plan returns when its result block lands, which may be before the stream has drained (the graph's tail — e.g. the
+    // early-exit kernels behind an early stop — still reads the workspace and the pinned blocks freed below)
+    if (hipStreamSynchronize(h->stream) != hipSuccess) (void)hipGetLastError();
     if (h->scratch) hipFree(h->scratch);
     if (h->comm) { if (Rccl *r = rccl()) r->CommDestroy(h->comm); h->comm = nullptr; }
     if (h->gexec) hipGraphExecDestroy(h->gexec);
@@ -1092,8 +1103,11 @@ int enqueue_rollout(cem_planner *h, int it, bool fold_reduce)
     rp.pad_shift = d.O - 4 * d.act_q0; rp.pad_floats = 4 * d.act_nq; rp.N = d.N; rp.Nloc = d.Nloc; rp.n_off = d.n_off; rp.n_tiles = h->n_tiles;
     if (!h->sample_in_rollout) {                          // all N candidates once, in front of the rollout launch (which then samples nothing)
         const int total = d.N * d.H * ((d.A + 3) / 4);
+        size_t es = 0;
+        if (h->timing) { es = h->ev_kind.size() * 2; h->ev_kind.push_back({(int)es, 3}); hipEventRecord(get_event(h, es), h->stream); }
         hipLaunchKernelGGL(cem_sample_kernel, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, h->stream, rp);
         HIPCHK(hipGetLastError());
+        if (h->timing) hipEventRecord(get_event(h, es + 1), h->stream);
         rp.musig = nullptr;
     }
     size_t e0 = 0;
@@ -1114,8 +1128,11 @@ int enqueue_rollout(cem_planner *h, int it, bool fold_reduce)
     qp.Nloc = d.Nloc; qp.P = d.P; qp.H = d.H; qp.variant = h->cfg.variant; qp.check_done = 1;
     qp.alpha = h->alpha; qp.beta = h->beta; qp.thr = h->cfg.posterior_mean_threashold;
     qp.zero = (uint32_t *)(ws + l.ms_hist); qp.zero_n = (3 * CEM_MS_BINS * 4 + 256) / 4; h->sel_zeroed = true;     // for this iteration's multi-workgroup select
+    size_t er = 0;
+    if (h->timing) { er = h->ev_kind.size() * 2; h->ev_kind.push_back({(int)er, 2}); hipEventRecord(get_event(h, er), h->stream); }
     hipLaunchKernelGGL(cem_reduce_kernel, dim3((d.Nloc + 63) / 64), dim3(CEM_REDUCE_THREADS), 0, h->stream, qp);
     HIPCHK(hipGetLastError());
+    if (h->timing) hipEventRecord(get_event(h, er + 1), h->stream);
     return CEM_OK;
 }
 
@@ -1156,7 +1173,7 @@ int enqueue_select(cem_planner *h, int it, bool fold_reduce, bool fold_final = f
     // for the few microseconds of the launch; under contention a barrier times out (bounded polls) and the plan fails with
     // CEM_ERR_DEVICE rather than hanging.  select_mode 2 has no such assumption.
     const int G = (d.N + CEM_MS_KEYS - 1) / CEM_MS_KEYS;
-    const bool can_fuse = G <= h->fused_resident;
+    const bool can_fuse = G <= h->fused_resident && !h->fuse_banned;
     bool cache = false;
     const int mode = resolve_select_mode(h->cfg.select_mode, d.N, d.k, (long long)d.H * d.A, h->sel_dyn_limit, can_fuse, &cache);
     if (mode == 0) return CEM_ERR_UNSUPPORTED;          // (an explicit select_mode 1 on a device that grants less dynamic LDS than validate() assumed)
@@ -1174,8 +1191,11 @@ int enqueue_select(cem_planner *h, int it, bool fold_reduce, bool fold_final = f
         // same iteration has already cleared them (ReduceParams::zero), this memset covers a select called on its own
         if (!h->sel_zeroed) HIPCHK(hipMemsetAsync(m.hist, 0, 3 * CEM_MS_BINS * 4 + 256, h->stream));
         h->sel_zeroed = false;
-        if (mode == 3) hipLaunchKernelGGL(cem_msel_fused_kernel, dim3(m.G), dim3(1024), 0, h->stream, m);
-        else {
+        if (mode == 3) {
+            hipLaunchKernelGGL(cem_msel_fused_kernel, dim3(m.G), dim3(1024), 0, h->stream, m);
+            // returns at once unless a grid barrier of the launch above expired; then it redoes this iteration's select alone (cem_device.h)
+            hipLaunchKernelGGL(cem_msel_solo_kernel, dim3(1), dim3(1024), 0, h->stream, m);
+        } else {
             hipLaunchKernelGGL(cem_msel_hist_kernel<0>, dim3(m.G), dim3(1024), 0, h->stream, m);
             hipLaunchKernelGGL(cem_msel_hist_kernel<1>, dim3(m.G), dim3(1024), 0, h->stream, m);
             hipLaunchKernelGGL(cem_msel_hist_kernel<2>, dim3(m.G), dim3(1024), 0, h->stream, m);
@@ -1188,7 +1208,7 @@ int enqueue_select(cem_planner *h, int it, bool fold_reduce, bool fold_final = f
     } else {
         if (fold_final) {
             p.is_last = it == d.I - 1;
-            p.result = h->d_h_result; p.eps_out = have_eps_out ? (const float *)(ws + l.eps_out) : nullptr; p.noise_stddev = h->cfg.noise_stddev;
+            p.result = h->d_h_result; p.result_dev = (uint32_t *)(ws + l.result); p.eps_out = have_eps_out ? (const float *)(ws + l.eps_out) : nullptr; p.noise_stddev = h->cfg.noise_stddev;
             if (folded) *folded = true;
         }
         if (cache) lds += (size_t)CEM_SEL_KWORDS(d.N) * 4;
@@ -1215,7 +1235,7 @@ int enqueue_end(cem_planner *h, bool have_eps_out)
 {
     const Dims &d = h->d; const Layout &l = h->lay; char *ws = h->ws;
     FinalParams fp{}; fp.ctrl = (const CtrlBlock *)(ws + l.ctrl); fp.eps_out = have_eps_out ? (const float *)(ws + l.eps_out) : nullptr;
-    fp.result = h->d_h_result; fp.A = d.A; fp.noise_stddev = h->cfg.noise_stddev;       // pinned host memory: no copy node behind the kernel
+    fp.result = h->d_h_result; fp.result_dev = (uint32_t *)(ws + l.result); fp.A = d.A; fp.noise_stddev = h->cfg.noise_stddev;       // pinned host memory: no copy node behind the kernel
     hipLaunchKernelGGL(cem_final_kernel, dim3(1), dim3(64), 0, h->stream, fp);
     HIPCHK(hipGetLastError());
     return CEM_OK;
@@ -1223,11 +1243,14 @@ int enqueue_end(cem_planner *h, bool have_eps_out)
 
 void collect_timing(cem_planner *h)
 {
-    h->roll_ms = 0.f; h->sel_ms = 0.f; h->roll_n = 0;
+    h->roll_ms = 0.f; h->sel_ms = 0.f; h->red_ms = 0.f; h->samp_ms = 0.f; h->roll_n = 0;
     for (auto &ek : h->ev_kind) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, h->ev[ek.first], h->ev[ek.first + 1]) == hipSuccess) {
-            if (ek.second == 0) { h->roll_ms += ms; h->roll_n++; } else h->sel_ms += ms;
+            if (ek.second == 0) { h->roll_ms += ms; h->roll_n++; }
+            else if (ek.second == 1) h->sel_ms += ms;
+            else if (ek.second == 2) h->red_ms += ms;
+            else h->samp_ms += ms;
         }
     }
     h->ev_kind.clear();
@@ -1241,6 +1264,7 @@ void stage_ctrl(cem_planner *h, const float *state, uint64_t seed, uint64_t call
     for (int f = 0; f < CEM_U; ++f) c->state[f] = f < h->d.O ? state[f] : 0.f;
     for (int a = 0; a < 32; ++a) c->best[a] = 0.f;
     c->seq = ++h->plan_seq;                             // echoed into result[36] by the kernel that completes the plan
+    c->inject = h->inject_next; h->inject_next = 0;     // (test hook, cem_planner_inject_fault)
 }
 
 // The plan is queued: wait for its result.  The kernel that completes it stores the plan counter into pinned host memory after
@@ -1252,9 +1276,7 @@ bool result_landed(const cem_planner *h)
 {
     const volatile uint32_t *r = reinterpret_cast<const volatile uint32_t *>(h->h_result);
     if (r[36] != h->plan_seq) return false;
-    uint32_t x = CEM_RESULT_MAGIC ^ h->plan_seq;
-    for (int i = 0; i < 36; ++i) x ^= r[i];
-    return x == r[37];
+    return cem_result_checksum(r, h->plan_seq) == r[37];      // position dependent: stale words cannot cancel (cem_device.h)
 }
 
 int wait_result(cem_planner *h)
@@ -1283,7 +1305,22 @@ int read_result(cem_planner *h, float *action_out, float *best_score_out, int32_
     if (action_out) std::memcpy(action_out, h->h_result, h->d.A * 4);
     if (best_score_out) *best_score_out = h->h_result[32];
     if (iters_out) *iters_out = reinterpret_cast<int32_t *>(h->h_result)[33];
-    return reinterpret_cast<int32_t *>(h->h_result)[35] ? CEM_ERR_DEVICE : CEM_OK;     // a kernel gave up (CtrlBlock::fault)
+    const int32_t fault = reinterpret_cast<int32_t *>(h->h_result)[35];                 // CtrlBlock::fault
+    if (fault & CEM_FAULT_RECOVERED) {
+        // A grid barrier of the fused select expired (its workgroups were not all resident: another stream, handle or process held
+        // CUs) and cem_msel_solo_kernel redid that iteration's select in stream order: the plan is valid, with select_mode 2's bits.
+        // This handle stops fusing: the next plan re-captures its graph on the eight-launch chain, which has no residency assumption.
+        if (!h->fuse_banned) {
+            std::fprintf(stderr, "cem_mpc: a grid barrier of the fused select timed out (GPU shared with other work?); that iteration's select was redone "
+                                 "by the recovery kernel and this handle uses the multi-launch select (select_mode 2) from now on\n");
+            h->fuse_banned = true;
+            if (hipStreamSynchronize(h->stream) != hipSuccess) (void)hipGetLastError();      // the graph may still be draining behind the polled result
+            if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+            if (h->graph) { hipGraphDestroy(h->graph); h->graph = nullptr; }
+            h->graph_ready = false;
+        }
+    }
+    return (fault & (CEM_FAULT_SEGMENT | CEM_FAULT_BARRIER)) ? CEM_ERR_DEVICE : CEM_OK;     // a kernel gave up and nothing made up for it
 }
 
 }  // namespace
@@ -1456,8 +1493,8 @@ int cem_planner_launches_per_iteration(const cem_planner_t *h, int32_t *launches
     if (!h || !launches_out) return CEM_ERR_INVALID_ARG;
     const Dims &d = h->d;
     const int G = (d.N + CEM_MS_KEYS - 1) / CEM_MS_KEYS;
-    const int mode = resolve_select_mode(h->cfg.select_mode, d.N, d.k, (long long)d.H * d.A, h->sel_dyn_limit, G <= h->fused_resident, nullptr);
-    *launches_out = 1 + (h->sample_in_rollout ? 0 : 1) + (folds_reduce(h) ? 0 : 1) + (mode == 2 ? 8 : 1);
+    const int mode = resolve_select_mode(h->cfg.select_mode, d.N, d.k, (long long)d.H * d.A, h->sel_dyn_limit, G <= h->fused_resident && !h->fuse_banned, nullptr);
+    *launches_out = 1 + (h->sample_in_rollout ? 0 : 1) + (folds_reduce(h) ? 0 : 1) + (mode == 2 ? 8 : (mode == 3 ? 2 : 1));
     return CEM_OK;
 }
 
@@ -1599,6 +1636,23 @@ int cem_philox_words(cem_planner_t *h, uint64_t seed, uint64_t call, uint32_t st
     return CEM_OK;
 }
 
+int cem_planner_select_mode(const cem_planner_t *h, int32_t *mode_out)
+{
+    if (!h || !mode_out) return CEM_ERR_INVALID_ARG;
+    const Dims &d = h->d;
+    const int G = (d.N + CEM_MS_KEYS - 1) / CEM_MS_KEYS;
+    *mode_out = resolve_select_mode(h->cfg.select_mode, d.N, d.k, (long long)d.H * d.A, h->sel_dyn_limit, G <= h->fused_resident && !h->fuse_banned, nullptr);
+    return CEM_OK;
+}
+
+int cem_planner_inject_fault(cem_planner_t *h, int32_t kind)
+{
+    if (!h || kind != 1) return CEM_ERR_INVALID_ARG;
+    if (h->in_plan) return CEM_ERR_STATE;
+    h->inject_next = 1u;            // staged with the next plan's control block (stage_ctrl) and consumed by it
+    return CEM_OK;
+}
+
 int cem_planner_set_timing(cem_planner_t *h, int32_t enable)
 {
     if (!h) return CEM_ERR_INVALID_ARG;
@@ -1612,6 +1666,14 @@ int cem_planner_last_timing(cem_planner_t *h, float *rollout_ms_total, int32_t *
     if (rollout_ms_total) *rollout_ms_total = h->roll_ms;
     if (rollout_launches) *rollout_launches = h->roll_n;
     if (select_ms_total) *select_ms_total = h->sel_ms;
+    return CEM_OK;
+}
+
+int cem_planner_last_timing_detail(cem_planner_t *h, float *reduce_ms_total, float *sampler_ms_total)
+{
+    if (!h) return CEM_ERR_INVALID_ARG;
+    if (reduce_ms_total) *reduce_ms_total = h->red_ms;
+    if (sampler_ms_total) *sampler_ms_total = h->samp_ms;
     return CEM_OK;
 }
 

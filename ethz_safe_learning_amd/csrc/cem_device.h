@@ -65,11 +65,15 @@ struct CtrlBlock {
     int32_t done;            // early stop reached (cem_mpc.py:66-67)
     int32_t iters;           // iterations run
     float best_score;        // best_so_far_score (cem_mpc.py:42)
-    int32_t fault;           // set by a kernel that had to give up (cem_rollout_seg_kernel's bounded spin); reported as CEM_ERR_DEVICE
+    int32_t fault;           // bit 0: a floating rollout segment never got its work-queue entry (bounded spin) -> CEM_ERR_DEVICE; bit 1: a grid
+                             // barrier of the fused select expired and the iteration's select has NOT been redone yet; bit 2: it expired and
+                             // cem_msel_solo_kernel redid that select (same bits as select_mode 2): the plan is valid, the host stops fusing
     float state[CEM_U];      // the observation (cem_mpc.py:32)
     float best[32];          // best_so_far (cem_mpc.py:41)
     uint32_t seq;            // the host's plan counter: the kernel that completes the plan's result echoes it into result[36] LAST, so
                              // the host can watch pinned memory for it instead of going through a stream synchronisation
+    uint32_t inject;         // test hook (cem_planner_inject_fault): 1 = the first grid barrier of this plan's first fused select expires on its
+                             // last workgroup as if it had been starved — exercises the recovery path without loading the GPU
 };
 
 struct ScorerDev {
@@ -986,7 +990,7 @@ __global__ __launch_bounds__(256) void cem_rollout_seg_kernel(const RolloutParam
             while ((v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && ++spins < CEM_SEG_SPIN_LIMIT)
                 __builtin_amdgcn_s_sleep(16);
             item = v ? v - 1u : 0xffffffffu;               // never filled within the limit: give up rather than hang the device ...
-            if (!v) atomicOr(const_cast<int32_t *>(&p.ctrl->fault), 1);   // ... and say so: the host returns CEM_ERR_DEVICE for this plan
+            if (!v) atomicOr(const_cast<int32_t *>(&p.ctrl->fault), 1 /* CEM_FAULT_SEGMENT */);   // ... and say so: the host returns CEM_ERR_DEVICE for this plan
         }
         item_s = item;
     }
@@ -1229,12 +1233,21 @@ __device__ __forceinline__ float cem_out_noise(const CtrlBlock *ctrl, const floa
 // block carries a checksum and the host accepts it only when counter and checksum both match.  One wave stores the block from an LDS copy.
 #define CEM_RESULT_WORDS 38
 #define CEM_RESULT_MAGIC 0x5EC0DE5Au
-__device__ __forceinline__ void cem_emit_result(float *result, const uint32_t *res_l /* LDS [36] */, const uint32_t seq, const int lane)
+// checksum of the block: FNV-1a over its 36 data words, seeded with the plan counter — position dependent (a plain XOR lets two stale
+// words cancel: iters 5 -> 4 together with done 0 -> 1), the same function on the host (cem_capi.hip result_landed)
+__host__ __device__ inline uint32_t cem_result_checksum(const volatile uint32_t *w, const uint32_t seq)
 {
     uint32_t x = CEM_RESULT_MAGIC ^ seq;
-    for (int i = 0; i < 36; ++i) x ^= res_l[i];
+    for (int i = 0; i < 36; ++i) x = (x ^ w[i]) * 0x01000193u;
+    return x ^ (x >> 15);
+}
+// `result`: the pinned host block; `result_dev`: the same 38 words in the workspace (cem_layout_t::result) for callers that stay on the device
+__device__ __forceinline__ void cem_emit_result(float *result, uint32_t *result_dev, const uint32_t *res_l /* LDS [36] */, const uint32_t seq, const int lane)
+{
+    const uint32_t x = cem_result_checksum(res_l, seq);
     if (lane < CEM_RESULT_WORDS) {
         const uint32_t w = lane < 36 ? res_l[lane] : (lane == 36 ? seq : x);
+        if (result_dev) result_dev[lane] = w;
         __hip_atomic_store(reinterpret_cast<uint32_t *>(result) + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -1245,7 +1258,7 @@ struct SelectParams {
     // score[i] = (sum over q = 0..P-1, in that order, of ret[q * N + i]) / P  (mpc_policy.py:38-39), also stored to scores_w[i]
     const float *ret; float *scores_w; int32_t P;
     // the plan's result written by the select itself (whole plans on this kernel: no final kernel; see FinalParams): null = not here
-    float *result; const float *eps_out; float noise_stddev;
+    float *result; uint32_t *result_dev; const float *eps_out; float noise_stddev;
     int32_t is_last;             // this is the plan's last iteration: with `result`, the completion marker (result[36] = ctrl->seq) follows the result
     int32_t N, k, HA, A, check_done;
     float smoothing, one_minus_smoothing, threshold;   // one_minus_smoothing = fl32(1.0 - smoothing) rounded once, as cem_mpc.py:64-65 does
@@ -1716,7 +1729,7 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
     }
     if (p.result) {
         __syncthreads();
-        if (tid < 64 && res_l[36]) cem_emit_result(p.result, res_l, p.ctrl->seq, tid);
+        if (tid < 64 && res_l[36]) cem_emit_result(p.result, p.result_dev, res_l, p.ctrl->seq, tid);
     }
 }
 
@@ -1939,77 +1952,95 @@ __global__ __launch_bounds__(256) void cem_msel_final_kernel(const MSelParams p)
 // action, mu and sigma are bit-identical to the chain's), separated by grid barriers instead of kernel boundaries.  The chain's
 // eight launches cost a fixed ~40 us, which made it lose to the one-workgroup kernel below ~30 000 keys; a grid barrier is one
 // atomic and a short poll.  A thread keeps its four keys in registers across all phases (the chain re-reads the scores three
-// times).  All G = ceil(N / 4096) workgroups must be resident at once: the host only takes this form when G <= the CU count
-// (one 1024-thread workgroup always fits a CU), and every poll is bounded — a barrier that does not complete sets ctrl->fault
-// (the plan then fails with CEM_ERR_DEVICE) instead of hanging the device.
+// times).  All G = ceil(N / 4096) workgroups must be resident at once: the host only takes this form when G <= what the runtime says
+// the device keeps resident of this kernel, and every poll is bounded — a barrier that does not complete (CUs held by other work)
+// sets CEM_FAULT_BARRIER instead of hanging the device; the launch then commits NOTHING of the optimiser's state, and
+// cem_msel_solo_kernel, launched right behind it, redoes the iteration's select from the same scores (round 5; before, the plan
+// failed with CEM_ERR_DEVICE).
 // Data that crosses workgroups INSIDE the launch (histograms, slice counts, the elite list, moment partial sums, slice bests)
 // is written and read at the device coherence point (agent-scope relaxed atomics = sc1 accesses; no cache maintenance), every
 // wave drains its stores (s_waitcnt vmcnt(0)) before its workgroup arrives at a barrier: the XCDs' L2s are not coherent with
 // each other for plain accesses (MI355X_MICROARCH.md, correctness boundaries).
 // ---------------------------------------------------------------------------------------------------------
 #define CEM_GRID_SPIN_LIMIT (1u << 22)
-__device__ __forceinline__ void cem_grid_barrier(uint32_t *ctr, const uint32_t target, CtrlBlock *ctrl)
+#define CEM_FAULT_SEGMENT 1          // CtrlBlock::fault bits
+#define CEM_FAULT_BARRIER 2
+#define CEM_FAULT_RECOVERED 4
+// `may_fault`: whether an expired poll of THIS workgroup invalidates the select.  False only at the last barrier for the workgroups that
+// have nothing left to do after it (all but workgroup 0): whether the tail commits must depend on workgroup 0's own view alone — a
+// late report from a workgroup that is about to exit, after the tail has committed, would have the recovery kernel redo a select
+// whose smoothing blend has already been applied.  `inject`: test hook (CtrlBlock::inject), this workgroup behaves as if starved.
+__device__ __forceinline__ void cem_grid_barrier(uint32_t *ctr, const uint32_t target, CtrlBlock *ctrl, const bool may_fault = true, const bool inject = false)
 {
-    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): this wave's sc1 stores / atomics are acknowledged
+    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): this wave's sc1 stores / atomics (a fault report included) are acknowledged
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t spins = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < CEM_GRID_SPIN_LIMIT) __builtin_amdgcn_s_sleep(1);
-        if (spins >= CEM_GRID_SPIN_LIMIT) atomicOr(&ctrl->fault, 2);
+        uint32_t spins = inject ? CEM_GRID_SPIN_LIMIT : 0u;
+        while (spins < CEM_GRID_SPIN_LIMIT && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) { ++spins; __builtin_amdgcn_s_sleep(1); }
+        if (spins >= CEM_GRID_SPIN_LIMIT && may_fault) atomicOr(&ctrl->fault, CEM_FAULT_BARRIER);
     }
     __syncthreads();
 }
 #define CEM_LDC(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define CEM_STC(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
-__global__ __launch_bounds__(1024) void cem_msel_fused_kernel(const MSelParams p)
+// The multi-workgroup select as one body.  SOLO false: workgroup blockIdx.x of a grid of G plays slice blockIdx.x, phases separated by
+// grid barriers (cem_msel_fused_kernel).  SOLO true: ONE workgroup plays all G slices of every phase in turn, phases separated by
+// its own barrier (cem_msel_solo_kernel, the recovery form): the same per-slice arithmetic, the same summation orders — bit-identical
+// results, no residency assumption, several times slower.  A slice's four keys per thread stay in registers across the phases when a
+// workgroup owns one slice; the solo form re-reads the scores per phase (as select_mode 2's chain does).
+template <bool SOLO>
+__device__ __forceinline__ void cem_msel_body(const MSelParams &p, uint32_t *lh /* [CEM_MS_BINS] */, uint32_t *sh /* [20] */, uint32_t (*wsum)[16],
+                                              uint32_t *base /* [2] */, float *bsc /* [16] */, int *bix /* [16] */, float (*red)[4][64])
 {
-    __shared__ uint32_t lh[CEM_MS_BINS];
-    __shared__ uint32_t sh[20];
-    __shared__ uint32_t wsum[2][16];
-    __shared__ uint32_t base[2];
-    __shared__ float bsc[16];
-    __shared__ int bix[16];
-    __shared__ float red[4][4][64];
-    if (p.check_done && p.ctrl->done) return;             // uniform over the grid: set by the previous iteration's tail
     const int tid = threadIdx.x;
     const uint32_t G = (uint32_t)p.G;
+    const int vb0 = SOLO ? 0 : (int)blockIdx.x, vb1 = SOLO ? (int)G : (int)blockIdx.x + 1;
     uint32_t phase = 0;
+    const bool inject = !SOLO && p.ctrl->inject == 1u && p.ctrl->iters == 0 && blockIdx.x == G - 1u;
+#define CEM_MS_BARRIER(LAST_) do { if (SOLO) { __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads(); } \
+        else { ++phase; cem_grid_barrier(p.bar, G * phase, p.ctrl, !(LAST_) || blockIdx.x == 0, inject && phase == 1u); } } while (0)
 
-    // this thread's four keys (consecutive candidates: ascending order inside the thread, the thread order = candidate order)
+    // a slice's four keys per thread (consecutive candidates: ascending order inside the thread, the thread order = candidate order)
     uint32_t key[4]; float sc[4];
-    const int i0 = blockIdx.x * CEM_MS_KEYS + 4 * tid;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { sc[j] = i0 + j < p.N ? p.scores[i0 + j] : 0.f; key[j] = i0 + j < p.N ? cem_f2key(sc[j]) : 0u; }
+    int i0 = 0;
+#define CEM_MS_LOAD(VB_) do { i0 = (VB_) * CEM_MS_KEYS + 4 * tid; \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) { sc[j] = i0 + j < p.N ? p.scores[i0 + j] : 0.f; key[j] = i0 + j < p.N ? cem_f2key(sc[j]) : 0u; } } while (0)
+    if (!SOLO) CEM_MS_LOAD(vb0);
 
     // ---- three digit histograms (11 + 11 + 10 bits) of the order-preserving keys: per-workgroup LDS histogram -> global atomics
     uint32_t need = (uint32_t)p.k, b0 = 0, b1 = 0, b2 = 0;
-#pragma unroll
+#pragma unroll 1
     for (int pass = 0; pass < 3; ++pass) {
         if (pass == 1) cem_ms_find<true>(p.hist, CEM_MS_BINS, need, sh, b0, need);
         if (pass == 2) cem_ms_find<true>(p.hist + CEM_MS_BINS, CEM_MS_BINS, need, sh, b1, need);
-        for (int b = tid; b < CEM_MS_BINS; b += 1024) lh[b] = 0u;
-        __syncthreads();
+        for (int vb = vb0; vb < vb1; ++vb) {
+            if (SOLO) { __syncthreads(); CEM_MS_LOAD(vb); }          // (the previous slice's flush has read lh)
+            for (int b = tid; b < CEM_MS_BINS; b += 1024) lh[b] = 0u;
+            __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (i0 + j < p.N) {
-                if (pass == 0) atomicAdd(&lh[key[j] >> 21], 1u);
-                else if (pass == 1) { if ((key[j] >> 21) == b0) atomicAdd(&lh[(key[j] >> 10) & 2047u], 1u); }
-                else { if ((key[j] >> 10) == ((b0 << 11) | b1)) atomicAdd(&lh[key[j] & 1023u], 1u); }
-            }
-        __syncthreads();
-        for (int b = tid; b < CEM_MS_BINS; b += 1024) { const uint32_t c = lh[b]; if (c) atomicAdd(&p.hist[pass * CEM_MS_BINS + b], c); }
-        cem_grid_barrier(p.bar, G * ++phase, p.ctrl);
+            for (int j = 0; j < 4; ++j)
+                if (i0 + j < p.N) {
+                    if (pass == 0) atomicAdd(&lh[key[j] >> 21], 1u);
+                    else if (pass == 1) { if ((key[j] >> 21) == b0) atomicAdd(&lh[(key[j] >> 10) & 2047u], 1u); }
+                    else { if ((key[j] >> 10) == ((b0 << 11) | b1)) atomicAdd(&lh[key[j] & 1023u], 1u); }
+                }
+            __syncthreads();
+            for (int b = tid; b < CEM_MS_BINS; b += 1024) { const uint32_t c = lh[b]; if (c) atomicAdd(&p.hist[pass * CEM_MS_BINS + b], c); }
+        }
+        CEM_MS_BARRIER(false);
     }
     cem_ms_find<true>(p.hist + 2 * CEM_MS_BINS, 1024, need, sh, b2, need);
     const uint32_t T = (b0 << 21) | (b1 << 10) | b2;      // key of the k-th largest score; `need` keys equal to T are taken, lowest index first
 
     // ---- keys > T / == T per slice
     uint32_t ngt = 0, neq = 0;
+    for (int vb = vb0; vb < vb1; ++vb) {
+        if (SOLO) { __syncthreads(); CEM_MS_LOAD(vb); }
+        ngt = 0; neq = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) if (i0 + j < p.N) { ngt += key[j] > T; neq += key[j] == T; }
-    {
+        for (int j = 0; j < 4; ++j) if (i0 + j < p.N) { ngt += key[j] > T; neq += key[j] == T; }
         uint32_t a = ngt, b = neq;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
@@ -2018,23 +2049,30 @@ __global__ __launch_bounds__(1024) void cem_msel_fused_kernel(const MSelParams p
         if (tid == 0) {
             uint32_t x = 0, y = 0;
             for (int i = 0; i < 16; ++i) { x += wsum[0][i]; y += wsum[1][i]; }
-            CEM_STC(&p.wg_counts[2 * blockIdx.x], x); CEM_STC(&p.wg_counts[2 * blockIdx.x + 1], y);
+            CEM_STC(&p.wg_counts[2 * vb], x); CEM_STC(&p.wg_counts[2 * vb + 1], y);
         }
     }
-    cem_grid_barrier(p.bar, G * ++phase, p.ctrl);
+    CEM_MS_BARRIER(false);
 
     // ---- compaction: elite indices in ascending candidate order, ties lowest index first (tf.nn.top_k); best elite of the slice
-    {
-        uint32_t a = 0, b = 0;
-        for (int g = tid; g < (int)blockIdx.x; g += 1024) { a += CEM_LDC(&p.wg_counts[2 * g]); b += CEM_LDC(&p.wg_counts[2 * g + 1]); }
+    for (int vb = vb0; vb < vb1; ++vb) {
+        if (SOLO) {
+            __syncthreads(); CEM_MS_LOAD(vb);
+            ngt = 0; neq = 0;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
-        if ((tid & 63) == 0) { wsum[0][tid >> 6] = a; wsum[1][tid >> 6] = b; }
-        __syncthreads();
-        if (tid == 0) { uint32_t x = 0, y = 0; for (int i = 0; i < 16; ++i) { x += wsum[0][i]; y += wsum[1][i]; } base[0] = x; base[1] = y; }
-        __syncthreads();
-    }
-    {
+            for (int j = 0; j < 4; ++j) if (i0 + j < p.N) { ngt += key[j] > T; neq += key[j] == T; }
+        }
+        {
+            uint32_t a = 0, b = 0;
+            for (int g = tid; g < vb; g += 1024) { a += CEM_LDC(&p.wg_counts[2 * g]); b += CEM_LDC(&p.wg_counts[2 * g + 1]); }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
+            __syncthreads();
+            if ((tid & 63) == 0) { wsum[0][tid >> 6] = a; wsum[1][tid >> 6] = b; }
+            __syncthreads();
+            if (tid == 0) { uint32_t x = 0, y = 0; for (int i = 0; i < 16; ++i) { x += wsum[0][i]; y += wsum[1][i]; } base[0] = x; base[1] = y; }
+            __syncthreads();
+        }
         const uint32_t gt_before = base[0], eq_before = base[1];
         __syncthreads();
         uint32_t pre_gt, pre_eq;
@@ -2048,7 +2086,8 @@ __global__ __launch_bounds__(1024) void cem_msel_fused_kernel(const MSelParams p
                 bool take = key[j] > T;
                 if (key[j] == T) { take = eqr < need; ++eqr; }
                 if (take) {
-                    CEM_STC(&p.elite_idx[pos], i0 + j); ++pos;
+                    if (pos < (uint32_t)p.k) CEM_STC(&p.elite_idx[pos], i0 + j);              // (pos >= k only after an expired barrier: counts of another iteration)
+                    ++pos;
                     if (bi == 0x7fffffff || sc[j] > bs) { bs = sc[j]; bi = i0 + j; }          // ascending i: the first maximum is the lowest index
                 }
             }
@@ -2062,21 +2101,22 @@ __global__ __launch_bounds__(1024) void cem_msel_fused_kernel(const MSelParams p
         __syncthreads();
         if (tid == 0) {
             for (int i = 1; i < 16; ++i) { const float os = bsc[i]; const int oi = bix[i]; if (oi != 0x7fffffff && (bi == 0x7fffffff || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; } }
-            CEM_STC(&p.best_sc[blockIdx.x], bs); CEM_STC(&p.best_ix[blockIdx.x], bi);
+            CEM_STC(&p.best_sc[vb], bs); CEM_STC(&p.best_ix[vb], bi);
         }
     }
-    cem_grid_barrier(p.bar, G * ++phase, p.ctrl);
+    CEM_MS_BARRIER(false);
 
     // ---- moments over the elite set (tf.nn.moments: mean, then mean squared difference): the chain's decomposition — groups of
     //      256 elites, four sub-sums per group added in order 0..3, groups added in group order — with each quarter of a
     //      workgroup (256 threads) playing one of the chain's moment workgroups
     const int sb = tid >> 8, t256 = tid & 255, sub = t256 >> 6, lc = t256 & 63;
     const float fk = (float)p.k;
-    const int rounds = (p.G2 + (int)G * 4 - 1) / ((int)G * 4);
+    const int groups_per_round = SOLO ? 4 : (int)G * 4;
+    const int rounds = (p.G2 + groups_per_round - 1) / groups_per_round;
 #pragma unroll 1
     for (int ph = 0; ph < 2; ++ph) {
         for (int rd = 0; rd < rounds; ++rd) {
-            const int g2 = (rd * (int)G + (int)blockIdx.x) * 4 + sb;
+            const int g2 = SOLO ? rd * 4 + sb : (rd * (int)G + (int)blockIdx.x) * 4 + sb;
             const bool have = g2 < p.G2;
             const int e0 = g2 * CEM_MS_EPG, e1 = (e0 + CEM_MS_EPG < p.k) ? e0 + CEM_MS_EPG : p.k;
             for (int c0 = 0; c0 < p.HA; c0 += 64) {
@@ -2094,7 +2134,12 @@ __global__ __launch_bounds__(1024) void cem_msel_fused_kernel(const MSelParams p
                     for (int e = e0 + sub; e < e1; e += 32) {                      // 8 gathers in flight
                         float a[8];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) { const int ee = e + 4 * j; a[j] = ee < e1 ? p.actions[(size_t)CEM_LDC(&p.elite_idx[ee]) * p.HA + col] : 0.f; }
+                        for (int j = 0; j < 8; ++j) {
+                            const int ee = e + 4 * j;
+                            int ei = ee < e1 ? CEM_LDC(&p.elite_idx[ee]) : 0;
+                            ei = ei < 0 ? 0 : (ei >= p.N ? p.N - 1 : ei);          // (an expired barrier may leave another launch's word here: stay inside `actions`)
+                            a[j] = ee < e1 ? p.actions[(size_t)ei * p.HA + col] : 0.f;
+                        }
 #pragma unroll
                         for (int j = 0; j < 8; ++j) if (e + 4 * j < e1) acc = ph ? acc + (a[j] - mean) * (a[j] - mean) : acc + a[j];
                     }
@@ -2105,11 +2150,16 @@ __global__ __launch_bounds__(1024) void cem_msel_fused_kernel(const MSelParams p
                 __syncthreads();
             }
         }
-        cem_grid_barrier(p.bar, G * ++phase, p.ctrl);
+        CEM_MS_BARRIER(ph == 1);
     }
+#undef CEM_MS_BARRIER
+#undef CEM_MS_LOAD
 
-    // ---- tail (workgroup 0): smoothing, early stop, best-so-far — cem_msel_final_kernel's statements
-    if (blockIdx.x != 0) return;
+    // ---- tail (workgroup 0): smoothing, early stop, best-so-far — cem_msel_final_kernel's statements.  Nothing of the optimiser's
+    //      state (mu / sigma, iteration count, best-so-far, early stop) is touched before this point, and none of it is touched if a
+    //      barrier of this launch expired anywhere: the recovery kernel then redoes the whole select from the same scores.
+    if (!SOLO && blockIdx.x != 0) return;
+    if (!SOLO && (CEM_LDC(&p.ctrl->fault) & CEM_FAULT_BARRIER)) return;
     const float sm = p.smoothing, osm = p.one_minus_smoothing;
     for (int col = tid; col < p.HA; col += 1024) {
         float t = 0.f;
@@ -2136,13 +2186,43 @@ __global__ __launch_bounds__(1024) void cem_msel_fused_kernel(const MSelParams p
         }
     }
 }
+
+#define CEM_MSEL_SHARED() \
+    __shared__ uint32_t lh[CEM_MS_BINS]; __shared__ uint32_t sh[20]; __shared__ uint32_t wsum[2][16]; __shared__ uint32_t base[2]; \
+    __shared__ float bsc[16]; __shared__ int bix[16]; __shared__ float red[4][4][64]
+
+__global__ __launch_bounds__(1024) void cem_msel_fused_kernel(const MSelParams p)
+{
+    CEM_MSEL_SHARED();
+    if (p.check_done && p.ctrl->done) return;             // uniform over the grid: set by the previous iteration's tail
+    cem_msel_body<false>(p, lh, sh, wsum, base, bsc, bix, red);
+}
+
+// Recovery: launched behind every cem_msel_fused_kernel, one workgroup, returns at once unless a grid barrier of that launch expired
+// (CEM_FAULT_BARRIER: the fused kernel's workgroups were not all resident — another stream / process held CUs).  Then it redoes the
+// iteration's whole select from the same scores, alone, phase by phase — no residency assumption, the bits of select_mode 2 — clears the
+// fault and leaves CEM_FAULT_RECOVERED for the host, which logs it once and stops fusing on this handle (cem_capi.hip after_plan).
+// In stream order and rank-local: a sharded plan's collectives are not disturbed and no rank has to agree with another about it.
+__global__ __launch_bounds__(1024) void cem_msel_solo_kernel(const MSelParams p)
+{
+    CEM_MSEL_SHARED();
+    if (p.check_done && p.ctrl->done) return;
+    if (!(CEM_LDC(&p.ctrl->fault) & CEM_FAULT_BARRIER)) return;
+    for (int b = threadIdx.x; b < 3 * CEM_MS_BINS; b += 1024) CEM_STC(&p.hist[b], 0u);      // the expired launch left partial counts
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    cem_msel_body<true>(p, lh, sh, wsum, base, bsc, bix, red);
+    __syncthreads();
+    if (threadIdx.x == 0) { atomicAnd(&p.ctrl->fault, ~CEM_FAULT_BARRIER); atomicOr(&p.ctrl->fault, CEM_FAULT_RECOVERED); }
+}
+#undef CEM_MSEL_SHARED
 #undef CEM_LDC
 #undef CEM_STC
 
 // What a plan returns (cem_mpc.py:68: best_so_far + N(0, noise_stddev), and best_so_far_score), written where the HOST reads it:
 // `result` is pinned host memory (no device -> host copy node after the plan).  Layout: [0, A) action, [32] score, [33] iterations run,
-// [34] early-stop flag, [35] fault bits.
-struct FinalParams { const CtrlBlock *ctrl; const float *eps_out; float *result; int32_t A; float noise_stddev; };
+// [34] early-stop flag, [35] fault bits, [36] plan counter, [37] checksum (cem_result_checksum); the same words go to the workspace copy.
+struct FinalParams { const CtrlBlock *ctrl; const float *eps_out; float *result; uint32_t *result_dev; int32_t A; float noise_stddev; };
 
 __global__ void cem_final_kernel(const FinalParams p)
 {
@@ -2156,7 +2236,7 @@ __global__ void cem_final_kernel(const FinalParams p)
         res_l[33] = (uint32_t)p.ctrl->iters; res_l[34] = (uint32_t)p.ctrl->done; res_l[35] = (uint32_t)p.ctrl->fault;
     }
     __syncthreads();
-    if (a < 64) cem_emit_result(p.result, res_l, p.ctrl->seq, a);
+    if (a < 64) cem_emit_result(p.result, p.result_dev, res_l, p.ctrl->seq, a);
 }
 
 // the raw Philox4x32-7 words of n counters (idx0 + i, t | it << 16, sub | stream << 16, call_lo) — what cem_normal4 turns into four

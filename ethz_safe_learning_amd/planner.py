@@ -208,8 +208,14 @@ class CemPlanner:
         self.stream.synchronize()
 
     # ------------------------------------------------------------------ views
-    def _view(self, off, count, dtype):
+    # Views into the workspace (no copy).  plan() may return before the planner's stream has drained — it watches the pinned result
+    # block, not the stream (cem_mpc.h, cem_planner_plan) — and these arrays are written by the kernels behind that result, on a
+    # stream torch's current stream knows nothing about: every accessor therefore drains the planner's stream first.  sync=False is for
+    # callers that enqueue work on the planner's own stream (`with planner.stream_context():`), where stream order already holds.
+    def _view(self, off, count, dtype, sync=True):
         t = self._torch
+        if sync:
+            self.stream.synchronize()
         nb = count * t.tensor([], dtype=dtype).element_size()
         return self._ws_view[off:off + nb].view(dtype)
 
@@ -217,32 +223,37 @@ class CemPlanner:
     def n_local(self):
         return self.cfg.n_samples // self.cfg.world_size
 
-    def scores_local(self):
-        return self._view(self.layout.scores_local, self.n_local, self._torch.float32)
+    def scores_local(self, sync=True):
+        return self._view(self.layout.scores_local, self.n_local, self._torch.float32, sync)
 
-    def scores_global(self):
-        return self._view(self.layout.scores_global, self.cfg.n_samples, self._torch.float32)
+    def scores_global(self, sync=True):
+        return self._view(self.layout.scores_global, self.cfg.n_samples, self._torch.float32, sync)
 
-    def actions(self):
+    def actions(self, sync=True):
         c = self.cfg
-        return self._view(self.layout.actions, c.n_samples * c.horizon * c.act_dim, self._torch.float32).view(
+        return self._view(self.layout.actions, c.n_samples * c.horizon * c.act_dim, self._torch.float32, sync).view(
             c.n_samples, c.horizon, c.act_dim)
 
-    def mu_sigma(self):
+    def mu_sigma(self, sync=True):
         c = self.cfg
-        return self._view(self.layout.mu_sigma, 2 * c.horizon * c.act_dim, self._torch.float32).view(2, c.horizon, c.act_dim)
+        return self._view(self.layout.mu_sigma, 2 * c.horizon * c.act_dim, self._torch.float32, sync).view(2, c.horizon, c.act_dim)
 
-    def elite_idx(self):
-        return self._view(self.layout.elite_idx, self.cfg.n_elite, self._torch.int32)
+    def elite_idx(self, sync=True):
+        return self._view(self.layout.elite_idx, self.cfg.n_elite, self._torch.int32, sync)
 
-    def returns(self):
+    def returns(self, sync=True):
         c = self.cfg
-        return self._view(self.layout.returns, c.particles * self.n_local, self._torch.float32).view(c.particles, self.n_local)
+        return self._view(self.layout.returns, c.particles * self.n_local, self._torch.float32, sync).view(c.particles, self.n_local)
 
-    def costs(self):
+    def costs(self, sync=True):
         c = self.cfg
-        return self._view(self.layout.costs, c.horizon * c.particles * self.n_local, self._torch.uint8).view(
+        return self._view(self.layout.costs, c.horizon * c.particles * self.n_local, self._torch.uint8, sync).view(
             c.horizon, c.particles, self.n_local)
+
+    def result_block(self, sync=True):
+        """The last completed plan's result as the device keeps it (cem_layout_t.result): uint32 [38] — [0, A) action bits, [32] score
+        bits, [33] iterations, [34] early-stop flag, [35] fault bits, [36] plan counter, [37] checksum."""
+        return self._view(self.layout.result, 38, self._torch.int32, sync)
 
     # ------------------------------------------------------------------ sync hooks
     def set_weights(self, weights):
@@ -310,6 +321,17 @@ class CemPlanner:
 
     def plan_exchange(self):
         _capi.check(self.lib.cem_plan_exchange(self.h), 'cem_plan_exchange')
+
+    def select_mode(self):
+        """The select form the next iteration takes on this handle: 1 one workgroup, 2 the multi-launch chain, 3 the chain fused into one
+        launch (cem_planner_select_mode; 2 for good once a fused select had to be recovered)."""
+        m = C.c_int32()
+        _capi.check(self.lib.cem_planner_select_mode(self.h, C.byref(m)), 'cem_planner_select_mode')
+        return m.value
+
+    def inject_fault(self, kind=1):
+        """Test hook (cem_planner_inject_fault): the next plan's first fused select sees one of its grid barriers expire."""
+        _capi.check(self.lib.cem_planner_inject_fault(self.h, kind), 'cem_planner_inject_fault')
 
     # ------------------------------------------------------------------ planning
     def _noise_args(self, eps_act, eps_model):
@@ -461,7 +483,10 @@ class CemPlanner:
     def last_timing(self):
         r, n, s = C.c_float(), C.c_int32(), C.c_float()
         _capi.check(self.lib.cem_planner_last_timing(self.h, C.byref(r), C.byref(n), C.byref(s)), 'cem_planner_last_timing')
-        return dict(rollout_ms=float(r.value), rollout_launches=int(n.value), select_ms=float(s.value))
+        rd, sa = C.c_float(), C.c_float()
+        _capi.check(self.lib.cem_planner_last_timing_detail(self.h, C.byref(rd), C.byref(sa)), 'cem_planner_last_timing_detail')
+        return dict(rollout_ms=float(r.value), rollout_launches=int(n.value), select_ms=float(s.value), reduce_ms=float(rd.value),
+                    sampler_ms=float(sa.value))
 
     def tiles(self):
         """(chunks_per_tile, tiles[n,6]) of this handle's plan (host-side logic, no GPU call)."""

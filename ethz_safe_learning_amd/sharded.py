@@ -42,8 +42,11 @@ class ShardedCemDriver:
         # payload: N/G floats per rank (B5: 32 KB) -> latency bound; RCCL picks its one-shot small-message path.
         # The collective is issued with the planner's stream current, so it is ordered after the rollout/reduce
         # kernels and before the select kernel without any host synchronisation.
-        ctx = self.backend.stream_context() if hasattr(self.backend, 'stream_context') else contextlib.nullcontext()
-        with ctx:
+        if hasattr(self.backend, 'stream_context'):       # CemPlanner: stream order holds, the accessors need not drain the stream
+            with self.backend.stream_context():
+                dist.all_gather_into_tensor(self.backend.scores_global(sync=False), self.backend.scores_local(sync=False), group=self.group)
+            return
+        with contextlib.nullcontext():
             dist.all_gather_into_tensor(self.backend.scores_global(), self.backend.scores_local(), group=self.group)
 
     def plan(self, state, seed=0, call=0, eps_act=None, eps_model=None, eps_out=None):

@@ -66,10 +66,10 @@ def rehearsal_score_frames(planner, state, world, iterations, seed=0, call=0):
     for it in range(iterations):
         planner.plan_rollout(it)
         with torch.cuda.stream(planner.stream):
-            own = planner.scores_local().clone()
+            own = planner.scores_local(sync=False).clone()
             frames[it] = (own.unsqueeze(0) * jitter).reshape(N)
-            planner.scores_global().copy_(frames[it])
-            planner.scores_global()[planner.cfg.rank * nloc:(planner.cfg.rank + 1) * nloc].copy_(own)
+            planner.scores_global(sync=False).copy_(frames[it])
+            planner.scores_global(sync=False)[planner.cfg.rank * nloc:(planner.cfg.rank + 1) * nloc].copy_(own)
         planner.plan_select(it)
     planner.plan_end()
     torch.cuda.synchronize()

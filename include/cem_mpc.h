@@ -24,8 +24,9 @@
  *                                  fallback if it does not load; logged on stderr whenever it is honoured.
  *   CEM_FORCE_SAMPLER=tile|kernel  where cem_mpc.py:44-48 runs: as the rollout tiles' prologue or as a launch of its own (default: by the
  *                                  tile plan, see cem_planner_launches_per_iteration).
- *   CEM_ASSUME_CUS=<n>             price tile plans for n compute units (the GPU-less host helpers default to 256; on a device it
- *                                  overrides multiProcessorCount).
+ *   CEM_ASSUME_CUS=<n>             price tile plans for n compute units (the GPU-less host helpers default to 256).  It moves the tile
+ *                                  PLAN only (tile size, pinned / floating split — bit-identical results either way); residency decisions
+ *                                  (the fused select's grid, where the sampler runs) always use the device's real multiProcessorCount.
  *   CEM_NO_POLL                    cem_planner_plan waits for a captured plan with hipStreamSynchronize instead of polling the result block in
  *                                  pinned memory (polling spins one host core for the duration of the plan and returns ~10 us sooner).
  *   CEM_FORCE_GENERIC_ROLLOUT      every configuration on the width-generic rollout kernel;  CEM_TRAIN_GEMM_KERNEL: the GEMM-by-GEMM trainer.
@@ -55,7 +56,8 @@ enum cem_status {
     CEM_ERR_STATE = 7,           /* stepwise calls out of order, or a call that would clobber the state of a plan in flight */
     CEM_ERR_COMM = 8,            /* librccl could not be opened, or an RCCL call failed (cem_last_hip_error() holds the ncclResult_t) */
     CEM_ERR_DEVICE = 9           /* a kernel reported that it could not finish its work (a floating rollout segment never received its
-                                    work-queue entry within the spin bound): the plan's result is not valid */
+                                    work-queue entry within the spin bound; or a fused select's barrier expired AND its recovery did not
+                                    run): the plan's result is not valid */
 };
 
 enum cem_variant { CEM_VARIANT_CEM = 0 /* CemMpc */, CEM_VARIANT_SAFE = 1 /* SafeCemMpc */ };
@@ -131,9 +133,11 @@ typedef struct cem_config {
     int32_t select_mode;          /* 0 = auto; 1 = the one-workgroup select kernel (elite list + 2 H A floats must fit 140 KB of LDS, n_elite <= 24576:
                                    * else CEM_ERR_UNSUPPORTED — auto routes such shapes to 3 / 2 instead); 2 = the multi-workgroup chain of eight launches; 3 = that
                                    * chain as ONE launch with grid barriers: needs its ceil(N / 4096) workgroups resident at once (checked against the
-                                   * runtime's occupancy x CU count; else 2 is taken) and ASSUMES an otherwise idle GPU for the microseconds of the launch —
-                                   * CUs held by another stream / handle / process or a CU-masked queue can starve a barrier, which then times out and the
-                                   * plan returns CEM_ERR_DEVICE (never hangs; mode 2 has no such assumption) — what auto picks
+                                   * runtime's occupancy x CU count; else 2 is taken) and is FASTEST on an otherwise idle GPU — CUs held by another
+                                   * stream / handle / process or a CU-masked queue can starve a barrier, which then times out (bounded polls, never
+                                   * a hang); the launch then commits nothing, a one-workgroup recovery kernel queued right behind it redoes that
+                                   * iteration's select from the same scores with mode 2's bits, the plan completes normally (CEM_OK), one line goes
+                                   * to stderr and the handle uses mode 2 from then on (cem_planner_select_mode reports it) — what auto picks
                                    * from 24 000 candidates on (the replicated select of a many-GPU plan; below, mode 1 is faster).  Same elite set, best action and
                                    * early stop in every mode; 2 and 3 are bit-identical; mu / sigma of 1 vs 2 / 3 agree to fp32 rounding
                                    * (the moments are summed in a different, still fixed, order) */
@@ -153,7 +157,10 @@ typedef struct cem_layout {
     size_t elite_idx;      /* int32 [k]         — elite set of the last select, ascending index */
     size_t returns;        /* float [P*N/world] — per-row done-masked return of the last rollout */
     size_t costs;          /* uint8 [H][P*N/world] — per-step masked cost (safe variant) */
-    size_t result;         /* float [A] action, float best_score, int32 iters, int32 done */
+    size_t result;         /* uint32 [38]: the last completed plan's result as the final kernel left it, word for word the pinned-host block
+                            * cem_planner_plan reads: [0, A) action (float), [32] best score (float), [33] iterations run, [34] early-stop
+                            * flag, [35] fault bits, [36] the handle's plan counter, [37] checksum.  Valid after the handle's stream has
+                            * drained (see cem_planner_plan) */
     size_t stamps;         /* int64 [tiles][4][8] — cycle stamps of the last rollout; written only by -DCEM_STAMPS diagnostic builds */
     size_t total;
 } cem_layout_t;
@@ -196,7 +203,12 @@ int cem_planner_set_normaliser(cem_planner_t *h, const float *inputs_min, const 
 /* CemMpc.generate_action (cem_mpc.py:31-33): state[obs] (host) -> action[act] (host).
  * Noise: Philox4x32-7 keyed (seed, call) when the eps pointers are NULL, otherwise explicit
  * DEVICE tensors eps_act[I][N][H][A], eps_model[I][H][P*N][obs] and HOST eps_out[A]
- * (parity mode: "identical seeds" == identical noise tensors). */
+ * (parity mode: "identical seeds" == identical noise tensors).
+ * Ordering: a captured plan (use_graph) returns as soon as its result block has landed in pinned host memory (sequence number +
+ * checksum), which can be BEFORE the handle's stream has drained.  What it hands back on the host — action, score, iterations — is
+ * complete; the DEVICE arrays of cem_layout_t — mu_sigma, elite_idx, scores, actions, result — are ordered only by the stream: a
+ * caller that reads them synchronises the handle's stream first (the Python binding's accessors do).  cem_planner_destroy drains
+ * the stream itself. */
 int cem_planner_plan(cem_planner_t *h, const float *state, uint64_t seed, uint64_t call,
                      const float *eps_act_dev, const float *eps_model_dev, const float *eps_out_host,
                      float *action_out, float *best_score_out, int32_t *iters_out);
@@ -223,6 +235,13 @@ int cem_planner_comm_destroy(cem_planner_t *h);
 /* ranks of the handle's communicator as RCCL itself reports them (ncclCommCount); 0 without a communicator */
 int cem_planner_comm_ranks(const cem_planner_t *h, int32_t *n_ranks_out);
 int cem_plan_exchange(cem_planner_t *h);
+/* The select form the handle's next iteration takes (1 / 2 / 3, see cem_config_t::select_mode): what automatic resolves to on this device,
+ * and 2 once a fused select has had to be recovered on this handle. */
+int cem_planner_select_mode(const cem_planner_t *h, int32_t *mode_out);
+/* Test hook.  kind 1: in the NEXT plan's first iteration, the last workgroup of the fused select treats its first grid barrier as
+ * expired (as if its peers were not resident) — the recovery path then runs without having to load the GPU.  No effect on plans
+ * whose select is not fused. */
+int cem_planner_inject_fault(cem_planner_t *h, int32_t kind);
 /* 0: cem_planner_plan launches kernel by kernel; 1: it replays a captured hipGraph; 2: capturing was tried and is not supported
  * with this communicator / runtime (the plan then stays kernel by kernel — same results) */
 int cem_planner_graph_status(const cem_planner_t *h, int32_t *status_out);
@@ -230,7 +249,8 @@ int cem_planner_graph_status(const cem_planner_t *h, int32_t *status_out);
  * 2 = rollout (its tiles sample their own action sequences, cem_mpc.py:44-48) + select (which forms the particle mean of the CemMpc
  * objective itself, mpc_policy.py:38-39) — single-rank CemMpc plans whose tiles are all resident at once; + 1 where the sampler is a
  * launch of its own (tiles queue for slots), + 1 where the reduce kernel stays (SafeCemMpc's Beta filter, sharded plans, the
- * multi-workgroup selects), + 7 for select_mode 2's chain.  The stepwise calls always launch the reduce kernel. */
+ * multi-workgroup selects), + 1 for select_mode 3's recovery kernel (returns at once unless a barrier expired), + 7 for select_mode 2's
+ * chain.  The stepwise calls always launch the reduce kernel. */
 int cem_planner_launches_per_iteration(const cem_planner_t *h, int32_t *launches_out);
 
 /* TransitionModel.unfold_sequences (transition_model.py:64-77) as an API of its own:
@@ -270,6 +290,9 @@ int cem_philox_words(cem_planner_t *h, uint64_t seed, uint64_t call, uint32_t st
  * (enabled by cem_planner_set_timing(h, 1); costs one event pair per launch). */
 int cem_planner_set_timing(cem_planner_t *h, int32_t enable);
 int cem_planner_last_timing(cem_planner_t *h, float *rollout_ms_total, int32_t *rollout_launches, float *select_ms_total);
+/* the same plan's other launches: the particle-mean / Beta-filter kernel (where it is a launch of its own) and the sampler launch (where the
+ * sampler is not the rollout tiles' prologue); 0 where the plan has no such launch */
+int cem_planner_last_timing_detail(cem_planner_t *h, float *reduce_ms_total, float *sampler_ms_total);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Ensemble training on the device: MlpEnsemble.training_step / validation_step

@@ -44,8 +44,8 @@ def run(name, N, world, rank=0):
             ev[1 + 2 * it].record(st)
             if world > 1:
                 with torch.cuda.stream(st):
-                    pl.scores_global()[nloc:].copy_(frames[it, nloc:])
-                    pl.scores_global()[:nloc].copy_(pl.scores_local())
+                    pl.scores_global(sync=False)[nloc:].copy_(frames[it, nloc:])
+                    pl.scores_global(sync=False)[:nloc].copy_(pl.scores_local(sync=False))
             pl.plan_select(it)
             ev[2 + 2 * it].record(st)
         pl.plan_end()
@@ -63,8 +63,8 @@ def run(name, N, world, rank=0):
             pl.plan_rollout(it)
             if world > 1:
                 with torch.cuda.stream(st):
-                    pl.scores_global()[nloc:].copy_(frames[it, nloc:])
-                    pl.scores_global()[:nloc].copy_(pl.scores_local())
+                    pl.scores_global(sync=False)[nloc:].copy_(frames[it, nloc:])
+                    pl.scores_global(sync=False)[:nloc].copy_(pl.scores_local(sync=False))
             pl.plan_select(it)
         pl.plan_end()
         tm = pl.last_timing()

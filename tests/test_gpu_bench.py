@@ -41,7 +41,24 @@ def test_default_bench_line():
     assert r['config']['hip_graph'] is True and r['config']['launches_per_iteration'] == 2       # rollout + select per CEM iteration at B2
     # the other BASELINE configs ride along as labelled extras (value stays B2): B1, B3, B4 whole plans + one rank of B5's eight
     cf = r['configs']
-    assert set(cf) == {'B1', 'B3', 'B4', 'B5_rank'} and not any('error' in v for v in cf.values()), cf
+    policy = {'B2_safe', 'shipped_safe_cem_mpc', 'shipped_safe_cem_mpc_early_stop', 'shipped_cem_mpc', 'shipped_cem_mpc_early_stop'}
+    assert set(cf) == {'B1', 'B3', 'B4', 'B5_rank'} | policy and not any('error' in v for v in cf.values()), cf
+    # the reference's default policy (config/agents.yaml:11) and its shipped shapes, timed by the driver's own run
+    for name in policy:
+        c = cf[name]
+        assert c['workload'].startswith(name + ':') and c['hip_graph'] is True and abs(c['plans_per_s'] * c['ms_per_plan'] / 1e3 - 1.0) < 1e-6
+        assert 0.0 < c['rollout_share_of_plan'] < 1.0 and c['select_us_per_iteration'] > 1.0
+        safe = 'safe' in name
+        # SafeCemMpc keeps the reduce kernel (Beta filter): 3 launches per iteration, its time reported; CemMpc folds it into the select
+        assert c['launches_per_iteration'] == (3 if safe else 2), (name, c['launches_per_iteration'])
+        assert (c['reduce_us_per_iteration'] > 0.5) == safe, (name, c['reduce_us_per_iteration'])
+        full = {'B2_safe': 5, 'shipped_safe_cem_mpc': 9, 'shipped_cem_mpc': 10}
+        if name in full:
+            assert c['iterations_run_mean'] == full[name]
+        else:
+            assert 1 <= c['iterations_run_mean'] <= (9 if safe else 10)
+    assert cf['B2_safe']['ms_per_plan'] < 1.25 * r['ms_per_step'], 'SafeCemMpc at the headline shape costs more than 25 % over CemMpc'
+    assert r['weak_plans_per_s'] == r['value'] and r['weak_candidates_per_plan'] == 2000 and 'extras_timed_out' not in r
     rows = {'B1': 5 * 500, 'B3': 16 * 8192, 'B4': 8 * 4096}
     for name in ('B1', 'B3', 'B4'):
         c = cf[name]
@@ -90,6 +107,10 @@ def test_b5_leg_rehearsed_as_one_rank_of_eight():
     assert out.returncode == 0, out.stderr[-2000:]
     r = _json_line(out.stdout)
     _check(r, 5, 2)
+    # the literal metric, strong-scaled: N = 2000 candidates in total, 250 on this rank of eight, plain plans/s
+    b2s = r['b2_strong']
+    assert b2s['n_ranks'] == 8 and b2s['candidates_per_rank'] == 250 and b2s['scaling'] == 'strong' and b2s['unit'] == 'plans/s' and 'N=2000' in b2s['workload']
+    assert abs(b2s['plans_per_s'] * b2s['ms_per_plan'] / 1e3 - 1.0) < 1e-6 and b2s['plans_per_s'] > 200
     b5 = r['b5']
     assert b5['n_ranks'] == 8 and b5['candidates_per_rank'] == 8192 and b5['scaling'] == 'strong' and 'N=65536' in b5['workload']
     assert b5['tiles'] * b5['chunks_per_tile'] * 16 == 5 * 8192 and 'rehearsal' in b5['exchange']

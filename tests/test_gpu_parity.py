@@ -1075,6 +1075,70 @@ def test_select_modes_agree_on_a_whole_plan():
     np.testing.assert_array_equal(res[1][4], res[2][4])
 
 
+
+@pytest.mark.parametrize('graph', [False, True])
+@pytest.mark.parametrize('N,k,smoothing', [(6000, 600, 0.2), (40000, 4000, 0.0)])
+def test_fused_select_barrier_timeout_is_recovered_in_stream(N, k, smoothing, graph, capfd):
+    """A grid barrier of the fused select (select_mode 3) that expires — its workgroups were not all resident: the GPU is shared — no
+    longer fails the plan with CEM_ERR_DEVICE.  The launch commits nothing of the optimiser's state, the one-workgroup recovery kernel
+    queued behind it redoes that iteration's select from the same scores, the plan completes with select_mode 2's bits, one line goes
+    to stderr and the handle stops fusing (cem_mpc.py:56-67: a select that always completes).  The expiry is injected
+    (cem_planner_inject_fault: the last workgroup of the first iteration's fused select treats its first barrier as expired and runs
+    ahead on a partial histogram), not provoked by loading the GPU.  Smoothing 0.2 makes a double-applied blend visible."""
+    torch = _torch()
+    pb = hp.make_problem(seed=91)
+    H, P, E, I = 12, 5, 5, 4
+    res = {}
+    for mode in (2, 3):
+        _, pcfg = hp.configs(pb, N=N, H=H, P=P, E=E, k=k, I=I, variant='safe', post=0.3, noise=0.01, smoothing=smoothing, select_mode=mode, use_graph=graph)
+        pl = hp.make_planner(pb, pcfg)
+        assert pl.select_mode() == mode
+        if mode == 3:
+            if graph:
+                pl.plan(pb['state'], seed=4, call=0)                      # capture first: the injected plan then REPLAYS the graph
+                assert pl.graph_status() == 'graph'
+            capfd.readouterr()
+            pl.inject_fault(1)
+        a, s, it = pl.plan(pb['state'], seed=3, call=0)                   # must not raise CEM_ERR_DEVICE
+        res[mode] = (a, s, it, np.sort(pl.elite_idx().cpu().numpy()), pl.mu_sigma().cpu().numpy().copy())
+        if mode == 3:
+            err = capfd.readouterr().err
+            assert err.count('grid barrier of the fused select timed out') == 1, err
+            fault = int(pl.result_block().cpu().numpy()[35])
+            assert fault == 4, 'fault bits %d: expected "recovered" alone' % fault
+            assert pl.select_mode() == 2, 'the handle keeps fusing after a recovered expiry'
+            assert pl.graph_status() == 'eager'                           # the captured graph (fused launches) was dropped
+            # and the handle goes on, on the chain: same bits again, no second line, a fresh graph where one is asked for
+            a2, s2, it2 = pl.plan(pb['state'], seed=3, call=0)
+            np.testing.assert_array_equal(a2, a)
+            assert (s2, it2) == (s, it)
+            assert capfd.readouterr().err.count('timed out') == 0
+            assert pl.graph_status() == ('graph' if graph else 'eager')
+        pl.close()
+    np.testing.assert_array_equal(res[3][0], res[2][0])
+    assert res[3][1] == res[2][1] and res[3][2] == res[2][2] == I
+    np.testing.assert_array_equal(res[3][3], res[2][3])
+    np.testing.assert_array_equal(res[3][4], res[2][4])
+
+
+def test_device_result_block_mirrors_the_host_result():
+    """cem_layout_t.result: the words the final kernel hands to the host, kept on the device too (action, score, iterations, flags,
+    plan counter, checksum) — for callers that stay on the device after a plan.  Both ways a plan ends: the select that folds the final
+    kernel (single-rank CemMpc) and cem_final_kernel (SafeCemMpc)."""
+    torch = _torch()
+    pb = hp.make_problem(seed=92)
+    for variant in ('cem', 'safe'):
+        _, pcfg = hp.configs(pb, N=256, H=8, P=5, E=5, k=25, I=3, variant=variant, noise=0.02, use_graph=True)
+        pl = hp.make_planner(pb, pcfg)
+        for call in range(3):
+            a, s, it = pl.plan(pb['state'], seed=8, call=call)
+            blk = pl.result_block().cpu().numpy()
+            np.testing.assert_array_equal(blk[:2].view(np.float32), a)
+            assert blk[32:33].view(np.float32)[0] == np.float32(s) and blk[33] == it == 3 and blk[35] == 0
+            assert blk[36] == call + 1, 'plan counter'
+        pl.close()
+
+
 @pytest.mark.parametrize('units', [128, 40])
 @pytest.mark.parametrize('activation', ['tf.nn.tanh', 'tf.nn.sigmoid', 'tf.nn.elu', 'tf.nn.leaky_relu', 'tf.nn.softplus', 'tf.nn.selu'])
 def test_other_activations_match_oracle(activation, units):

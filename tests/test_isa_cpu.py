@@ -72,13 +72,21 @@ def test_fused_select_grid_barrier_drains_before_arriving(isa):
     assert len(bodies) == 1
     ins = next(iter(bodies.values()))
     # an arrival = the atomic add that is followed by the polling loop (sc1 load + s_sleep)
-    arrivals = [i for i, l in enumerate(ins) if l.startswith('global_atomic_add') and any(x.startswith('s_sleep') for x in ins[i + 1:i + 20])]
+    arrivals = [i for i, l in enumerate(ins) if l.startswith('global_atomic_add') and any(x.startswith('s_sleep') for x in ins[i + 1:i + 40])]
     assert len(arrivals) >= 4, arrivals      # the phases in loops share code: at least the histogram loop, counts, compaction, moments loop
     for a in arrivals:
         bar = max(i for i in range(a) if ins[i].startswith('s_barrier'))
         assert a - bar < 20, (a, bar)
         prev = ins[max(0, bar - 3):bar]
         assert any(x.startswith('s_waitcnt') and 'vmcnt(0)' in x for x in prev), (a, prev)
+    # the recovery form of the same body (one workgroup plays every slice): no arrivals, no polling — its phases are separated by
+    # the workgroup's own barrier, each behind a drain of the wave's stores
+    solo = _kernel_bodies(isa, r'cem_msel_solo_kernel')
+    assert len(solo) == 1
+    sins = next(iter(solo.values()))
+    assert not any(l.startswith('s_sleep') for l in sins), 'the solo select must not poll'
+    drained = [i for i, l in enumerate(sins) if l.startswith('s_barrier') and any(x.startswith('s_waitcnt') and 'vmcnt(0)' in x for x in sins[max(0, i - 3):i])]
+    assert len(drained) >= 5, len(drained)       # zeroing, histogram loop, counts, compaction, moments loop
 
 
 def _kernel_meta(isa, pattern):
