@@ -1155,7 +1155,7 @@ int enqueue_select(cem_planner *h, int it, bool fold_reduce, bool fold_final = f
     const Dims &d = h->d; const Layout &l = h->lay; char *ws = h->ws;
     SelectParams p{}; p.scores = (const float *)(ws + l.scores_global); p.actions = (const float *)(ws + l.actions);
     p.musig = (float *)(ws + l.musig); p.ctrl = (CtrlBlock *)(ws + l.ctrl); p.elite_idx = (int32_t *)(ws + l.elite);
-    p.N = d.N; p.k = d.k; p.HA = d.H * d.A; p.A = d.A; p.check_done = 1;
+    p.N = d.N; p.k = d.k; p.HA = d.H * d.A; p.A = d.A; p.check_done = 1; p.crowded = h->cfg.variant == CEM_VARIANT_SAFE;
     p.smoothing = h->cfg.smoothing; p.one_minus_smoothing = h->cfg.one_minus_smoothing; p.threshold = h->cfg.stddev_threshold;
     p.stamps = (long long *)(ws + l.stamps) + 64;          // past tile 0's rollout stamps; written by -DCEM_STAMPS builds only
     if (fold_reduce) { p.ret = (const float *)(ws + l.returns); p.P = d.P; p.scores_w = (float *)(ws + l.scores_local); }   // (folds_reduce(): world 1, so local == global)

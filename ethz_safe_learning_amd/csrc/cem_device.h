@@ -1057,56 +1057,88 @@ struct ReduceParams {
     uint32_t *zero; int32_t zero_n;        // words block 0 clears for the multi-workgroup select that follows (digit histograms + barrier counter), or null
 };
 
-// One block = 64 candidates x 16 waves.  Wave w counts the particle costs of steps t = w, w+16, ... (byte loads,
-// coalesced over the 64 candidates, 8 in flight per lane); wave 0 also forms the particle mean in the reference's
-// order q = 0..P-1.  Counts are small integers, exact in the reference's fp32 sums as well.
+// One block = 64 candidates (one per lane) x 16 waves.  The kernel is a latency chain — a few hundred bytes per candidate, one dependent
+// round of loads, a barrier, a store — so what matters is how many round trips to L2 a wave makes, not bandwidth (round 5, measured at
+// the shipped SafeCemMpc shape, P = 45, H = 8, where ten of the sixteen waves used to idle and the others made six trips each):
+//   * horizons of 16 steps and more: wave w counts the particle costs of steps t = w, w + 16, ..., TWO steps per trip, up to 8 particles each;
+//   * shorter horizons: the 16 waves share out (step, particle slice) pairs — 16 / H waves per step, each counting every (16 / H)-th
+//     particle, up to 16 loads per trip — and add their counts in LDS (integers: exact, order-free);
+//   * wave 0's return loads (the particle mean, summed in the reference's order q = 0 .. P-1) are requested before its cost loads.
+// Counts are small integers, exact in the reference's fp32 sums as well.
 #define CEM_REDUCE_THREADS 1024
 __global__ __launch_bounds__(CEM_REDUCE_THREADS) void cem_reduce_kernel(const ReduceParams p)
 {
     __shared__ int32_t unsafe_w[16][64];
+    __shared__ uint32_t cnt_s[16][64];
     if (p.check_done && p.ctrl->done) return;
     if (p.zero && blockIdx.x == 0) for (int i = threadIdx.x; i < p.zero_n; i += CEM_REDUCE_THREADS) p.zero[i] = 0u;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + lane;
     const bool live = n < p.Nloc;
     const int nn = live ? n : p.Nloc - 1;
+    const int P = p.P, H = p.H;
+    // wave 0: the first 16 particles' returns, in flight while the costs are counted
+    float r0[16];
+    if (w == 0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) r0[j] = p.ret[(size_t)(j < P ? j : 0) * p.Nloc + nn];
+    }
     int32_t unsafe = 0;
     if (p.variant == 1) {                                              // safe_cem_mpc.py:90-96,110-120
-        const float denom = (p.alpha + p.beta) + (float)p.P;
-        const size_t Bloc = (size_t)p.P * p.Nloc;
-        for (int t = w; t < p.H; t += 16) {
-            const uint8_t *c = p.costs + (size_t)t * Bloc + nn;
-            uint32_t cnt = 0;
-            int q = 0;
-            for (; q + 8 <= p.P; q += 8) {
-                uint32_t v[8];
+        const float denom = (p.alpha + p.beta) + (float)P;
+        const size_t Bloc = (size_t)P * p.Nloc;
+        if (H >= 16) {
+            for (int t = w; t < H; t += 32) {
+                const int t2 = t + 16 < H ? t + 16 : t;               // (clamped: the loads are unconditional, the second count is dropped)
+                const uint8_t *ca = p.costs + (size_t)t * Bloc + nn, *cb = p.costs + (size_t)t2 * Bloc + nn;
+                uint32_t cnta = 0, cntb = 0;
+                for (int q = 0; q < P; q += 8) {
+                    uint32_t va[8], vb[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = c[(size_t)(q + j) * p.Nloc];
+                    for (int j = 0; j < 8; ++j) { const size_t o = (size_t)(q + j < P ? q + j : q) * p.Nloc; va[j] = ca[o]; vb[j] = cb[o]; }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) cnt += v[j];
+                    for (int j = 0; j < 8; ++j) if (q + j < P) { cnta += va[j]; cntb += vb[j]; }
+                }
+                unsafe |= ((p.alpha + (float)cnta) / denom <= p.thr) ? 0 : 1;
+                if (t + 16 < H) unsafe |= ((p.alpha + (float)cntb) / denom <= p.thr) ? 0 : 1;
             }
-            for (; q < p.P; ++q) cnt += c[(size_t)q * p.Nloc];
-            const float post = (p.alpha + (float)cnt) / denom;
-            unsafe |= (post <= p.thr) ? 0 : 1;
+        } else {
+            const int wpt = 16 / H;                                    // waves per step (>= 1), H * wpt <= 16 of the waves count
+            cnt_s[w][lane] = 0u;
+            __syncthreads();
+            if (w < H * wpt) {
+                const int t = w / wpt, part = w % wpt;
+                const uint8_t *c = p.costs + (size_t)t * Bloc + nn;
+                uint32_t cnt = 0;
+                for (int q = part; q < P; q += 16 * wpt) {
+                    uint32_t v[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) { const int qq = q + j * wpt; v[j] = c[(size_t)(qq < P ? qq : q) * p.Nloc]; }
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) if (q + j * wpt < P) cnt += v[j];
+                }
+                if (wpt > 1) atomicAdd(&cnt_s[t][lane], cnt); else cnt_s[t][lane] = cnt;
+            }
+            __syncthreads();
+            if (w < H) unsafe = ((p.alpha + (float)cnt_s[w][lane]) / denom <= p.thr) ? 0 : 1;
         }
         unsafe_w[w][lane] = unsafe;
     }
     float sum = 0.f;
     if (w == 0) {
-        const float *r = p.ret + nn;
-        int q = 0;
-        for (; q + 8 <= p.P; q += 8) {
-            float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = r[(size_t)(q + j) * p.Nloc];
+        for (int j = 0; j < 16; ++j) if (j < P) sum = sum + r0[j];
+        for (int q = 16; q < P; q += 16) {
+            float v[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sum = sum + v[j];
+            for (int j = 0; j < 16; ++j) v[j] = p.ret[(size_t)(q + j < P ? q + j : q) * p.Nloc + nn];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) if (q + j < P) sum = sum + v[j];
         }
-        for (; q < p.P; ++q) sum = sum + r[(size_t)q * p.Nloc];
     }
     __syncthreads();
     if (w != 0 || !live) return;
-    float score = sum / (float)p.P;                                    // reduce_mean over particles
+    float score = sum / (float)P;                                      // reduce_mean over particles
     if (p.variant == 1) {
         int32_t u = 0;
 #pragma unroll
@@ -1261,6 +1293,7 @@ struct SelectParams {
     float *result; uint32_t *result_dev; const float *eps_out; float noise_stddev;
     int32_t is_last;             // this is the plan's last iteration: with `result`, the completion marker (result[36] = ctrl->seq) follows the result
     int32_t N, k, HA, A, check_done;
+    int32_t crowded;             // the scores have a crowd (SafeCemMpc: the unsafe candidates near -100): count buckets wave by wave (a speed hint only)
     float smoothing, one_minus_smoothing, threshold;   // one_minus_smoothing = fl32(1.0 - smoothing) rounded once, as cem_mpc.py:64-65 does
     long long *stamps;           // [8] section stamps of -DCEM_STAMPS diagnostic builds
 };
@@ -1457,16 +1490,37 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
             h2k[tid] = 0u; h2k[tid + 1024] = 0u;
             if (tid == 0) sh_cnt = 0u;
             __syncthreads();
-            for (int i = tid; i < N; i += 1024) {
-                const uint32_t off = ckey[CEM_SEL_KIDX(i)] - base;      // (a key below base wraps to a huge offset: out of the window)
-                if (off <= window) atomicAdd(&h2k[off >> sh], 1u);
+            if (p.crowded) {
+                // SafeCemMpc: most candidates are unsafe and their scores — return minus 100 — share ONE bucket.  Whole waves enter and the bucket
+                // of a wave's first key is added once for all the lanes that share it (one round: -0.7 us at B2; a second round gains nothing,
+                // and on CemMpc's spread-out scores the round costs 0.4 us for nothing: hence the flag, which the host sets by the objective)
+                for (int i0 = 0; i0 < N; i0 += 1024) {
+                    const int i = i0 + tid;
+                    const uint32_t off = i < N ? ckey[CEM_SEL_KIDX(i)] - base : 0xFFFFFFFFu;
+                    bool match = i < N && off <= window;
+                    const uint32_t digit = off >> sh;
+                    const uint64_t rem = __builtin_amdgcn_ballot_w64(match);
+                    if (rem) {
+                        const int leader = __builtin_ctzll(rem);
+                        const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)digit, leader);
+                        const uint64_t same = __builtin_amdgcn_ballot_w64(match && digit == d);
+                        if ((tid & 63) == leader) atomicAdd(&h2k[d], (uint32_t)__builtin_popcountll(same));
+                        if (digit == d) match = false;
+                    }
+                    if (match) atomicAdd(&h2k[digit], 1u);
+                }
+            } else {
+                for (int i = tid; i < N; i += 1024) {
+                    const uint32_t off = ckey[CEM_SEL_KIDX(i)] - base;      // (a key below base wraps to a huge offset: out of the window)
+                    if (off <= window) atomicAdd(&h2k[off >> sh], 1u);
+                }
             }
             __syncthreads();
             uint32_t bucket, need1;
             cem_ms_find<false>(h2k, 2048, need, sh20, bucket, need1);   // ge[bucket] >= need > ge[bucket + 1]; need1 = need - ge[bucket + 1]
             const uint32_t m = h2k[bucket];
             if (sh == 0) { prefix = base + bucket; need = need1; solved = true; break; }     // the bucket is ONE key: `need1` of its ties are taken
-            if (m <= 256u) {                                             // (workgroup-uniform)
+            if (m <= 32u) {                                              // (workgroup-uniform) a handful of keys — the usual CemMpc case: m threads rank them, one barrier fewer
                 for (int i = tid; i < N; i += 1024) {
                     const uint32_t key = ckey[CEM_SEL_KIDX(i)], off = key - base;
                     if (off <= window && (off >> sh) == bucket) { const uint32_t pos = atomicAdd(&sh_cnt, 1u); lkey[pos] = key; lidx[pos] = (uint32_t)i; }
@@ -1478,6 +1532,51 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
                     for (uint32_t l = 0; l < m; ++l) { const uint32_t kl = lkey[l]; gt += kl > kj; before += (kl > kj) || (kl == kj && lidx[l] < ij); }
                     if (before == need1 - 1u) { sh_prefix = kj; sh_need = need1 - gt; }     // the k-th largest; ties at its key still to take
                 }
+                __syncthreads();
+                prefix = sh_prefix; need = sh_need; solved = true;
+                break;
+            }
+            if (m <= 256u) {
+                // Collect the bucket's keys (a wave takes its slots with ONE returning atomic, lanes place themselves behind it), then rank
+                // them against each other with the whole workgroup: key j is compared with a quarter of the list by each of four threads and the
+                // partial counts meet in LDS (integers: order-free).  Round 5: with `m` threads walking all m keys alone, a SafeCemMpc
+                // iteration — 170 keys in the k-th key's bucket — spent 15 of the select's 27 us here (CemMpc: m is 1-5).
+                uint32_t *gt_s = &hist[0][0], *bf_s = &hist[1][0];       // [256] each (the radix passes below do not run once this path solves)
+                if (tid < 512) (&hist[0][0])[tid] = 0u;
+                for (int i0 = 0; i0 < N; i0 += 1024) {
+                    const int i = i0 + tid;
+                    const uint32_t key = i < N ? ckey[CEM_SEL_KIDX(i)] : 0u, off = key - base;
+                    const bool hit = i < N && off <= window && (off >> sh) == bucket;
+                    const uint64_t hits = __builtin_amdgcn_ballot_w64(hit);
+                    if (hits) {                                          // (wave-uniform)
+                        const int lane = tid & 63, leader = __builtin_ctzll(hits);
+                        uint32_t first = 0u;
+                        if (lane == leader) first = atomicAdd(&sh_cnt, (uint32_t)__builtin_popcountll(hits));
+                        first = (uint32_t)__builtin_amdgcn_readlane((int)first, leader);
+                        if (hit) { const uint32_t pos = first + (uint32_t)__builtin_popcountll(hits & ((1ull << lane) - 1ull)); lkey[pos] = key; lidx[pos] = (uint32_t)i; }
+                    }
+                }
+                __syncthreads();
+                {
+                    const uint32_t j = (uint32_t)tid & 255u, qtr = (uint32_t)tid >> 8, span = (m + 3u) >> 2;
+                    if (j < m) {
+                        const uint32_t kj = lkey[j], ij = lidx[j];
+                        const uint32_t lo = qtr * span, hi = lo + span < m ? lo + span : m;
+                        uint32_t gt = 0, before = 0;
+                        for (uint32_t l = lo; l < hi; l += 8) {           // eight (clamped, hence unconditional) LDS reads in flight: one latency per eight keys
+                            uint32_t kl[8], il[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) { const uint32_t lu = l + u < hi ? l + u : hi - 1u; kl[u] = lkey[lu]; il[u] = lidx[lu]; }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                if (l + u < hi) { gt += kl[u] > kj; before += (kl[u] > kj) || (kl[u] == kj && il[u] < ij); }
+                        }
+                        if (gt) atomicAdd(&gt_s[j], gt);
+                        if (before) atomicAdd(&bf_s[j], before);
+                    }
+                }
+                __syncthreads();
+                if ((uint32_t)tid < m && bf_s[tid] == need1 - 1u) { sh_prefix = lkey[tid]; sh_need = need1 - gt_s[tid]; }     // the k-th largest; ties at its key still to take
                 __syncthreads();
                 prefix = sh_prefix; need = sh_need; solved = true;
                 break;
@@ -1538,26 +1637,24 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
     for (int i = beg; i < end; ++i) { const uint32_t key = K(i); ngt += key > T; neq += key == T; }
     uint32_t pre_gt, pre_eq;
     cem_block_excl_scan2(ngt, neq, wsum, pre_gt, pre_eq);
+    // ... and, in the same walk, the best of elite: max score, first (= lowest candidate index) among exact ties (cem_mpc.py:57-60).  A thread
+    // sees its taken keys in ascending candidate order, so a strict `>` keeps the lowest index; threads and waves combine on (score, index).
+    // (Round 5: this was a pass of its own over the elite list behind the barrier — 0.8 of the select's 10 us.)  Per-wave candidates now;
+    // the final combine and the update of best-so-far run on wave 1 at the very end.
     {
         uint32_t eqr = pre_eq;
         uint32_t pos = pre_gt + (pre_eq < need ? pre_eq : need);
+        float bs = -__builtin_inff(); int bp = 0x7fffffff;               // bp: CANDIDATE index of this thread's best elite
         for (int i = beg; i < end; ++i) {
-            const uint32_t key = K(i);
+            const float scv = CACHE ? 0.f : p.scores[i];
+            const uint32_t key = CACHE ? ckey[CEM_SEL_KIDX(i)] : cem_f2key(scv);
             bool take = key > T;
             if (key == T) { take = eqr < need; ++eqr; }
-            if (take) { elite[pos] = i; p.elite_idx[pos] = i; ++pos; }
-        }
-    }
-    __syncthreads();
-
-    CEM_SEL_STAMP(3);
-    // ---- best of elite: max score, first (= lowest index) among exact ties  (cem_mpc.py:57-60) -------------
-    // per-wave candidates now; the final combine and the update of best-so-far run on wave 1 at the very end
-    {
-        float bs = -__builtin_inff(); int bp = 0x7fffffff;
-        for (int e = tid; e < k; e += 1024) {
-            const float sc = CACHE ? cem_key2f(ckey[CEM_SEL_KIDX(elite[e])]) : p.scores[elite[e]];
-            if (bp == 0x7fffffff || sc > bs) { bs = sc; bp = e; }
+            if (take) {
+                elite[pos] = i; p.elite_idx[pos] = i; ++pos;
+                const float sc = CACHE ? cem_key2f(key) : scv;
+                if (bp == 0x7fffffff || sc > bs) { bs = sc; bp = i; }
+            }
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
@@ -1566,6 +1663,9 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
         }
         if ((tid & 63) == 0) { bsc[tid >> 6] = bs; bpos[tid >> 6] = bp; }
     }
+    __syncthreads();
+
+    CEM_SEL_STAMP(3);
 
     CEM_SEL_STAMP(4);
     // ---- moments over the elite set (tf.nn.moments: mean, then mean squared difference) ---------------------
@@ -1710,7 +1810,7 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
             if (op != 0x7fffffff && (bp == 0x7fffffff || os > bs || (os == bs && op < bp))) { bs = os; bp = op; }
         }
         const bool better = bs > p.ctrl->best_score;                         // strict (cem_mpc.py:58)
-        const int idx = elite[bp];
+        const int idx = bp;                                                  // (candidate index: the compaction walk recorded it)
         for (int a0 = 0; a0 < p.A; a0 += 4) {
             f4 e = (f4){0.f, 0.f, 0.f, 0.f};                                                    // the output noise of these four actions: one draw
             if (p.result && !p.eps_out) e = cem_normal4((uint32_t)(a0 >> 2), 0u, 0u, 0u, CEM_STREAM_OUT, cem_key(p.ctrl));
