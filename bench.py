@@ -599,6 +599,7 @@ def main():
         'n_gpus': G, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
         'ms_per_step_median': float(np.median(step_ms)), 'ms_per_step_p90': float(np.percentile(step_ms, 90)),
         'value_at_median_step': (1e3 / float(np.median(step_ms))) * (N / 2000.0),
+        'ms_per_step_each': [round(float(x), 4) for x in step_ms[:64]],        # the timed steps one by one (the first 64): a cold GPU shows its clock ramp here
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'B2: obs=60 act=2 K=P=E=5 N=%d H=30 I=5 k=N/10 units=128 layers=4, CemMpc objective, early stop off%s'
                                % (N, '' if G == 1 else ' (weak-scaled: 2000 candidates per GPU, value in B2-equivalent plans/s)'),
