@@ -460,6 +460,7 @@ def main():
     ap.add_argument('--no-split-leg', action='store_true')
     ap.add_argument('--no-configs', action='store_true', help='skip the B1 / B3 / B4 / B5-rank extras of a single-GPU run')
     ap.add_argument('--no-b5', action='store_true', help='skip the B5 extras of a multi-GPU run')
+    ap.add_argument('--no-local-leg', action='store_true', help='multi-rank runs: skip the per-rank single-GPU B2 leg in front of the headline')
     ap.add_argument('--extras-timeout', type=int, default=240, help='seconds after which a multi-rank run prints its headline without the extras')
     ap.add_argument('--extras-timeout-status', type=int, default=0, help='exit status of a run whose extras timed out (the line then carries "extras_timed_out": true)')
     ap.add_argument('--no-graph', action='store_true')
@@ -535,6 +536,54 @@ def main():
         if not distributed or native:
             return pl.plan(pb['state'], seed=2026, call=i)
         return drv.plan(pb['state'], seed=2026, call=i)
+
+    # Single-GPU extras FIRST, the headline after them.  A GPU that has been idle ramps its clock over the first ~13 B2 plans (26 ms of work:
+    # 2.07 -> 1.89 ms per plan, profiles/r05_cold_start_steps.txt), which is most of what the driver's `--warmup 5 --steps 20` times; with the
+    # other legs in front, the W warm-up plans and the K timed plans of the headline run at the sustained clock — what "planning steps per
+    # second" means for a planner called in a loop.  Exactly W warm-up and K timed steps either way; `ms_per_step_each` lists every timed step.
+    pre = {}
+    if G == 1 and not distributed and not args.no_configs:
+        # the other single-GPU BASELINE configs (and one rank of B5's eight) on the driver's line: labelled extras, `value` stays B2
+        legs = {}
+        for name, O_, A_, K_, N_, H_, st_, wu_ in (('B1', 60, 2, 5, 500, 25, 60, 15), ('B3', 60, 2, 16, 8192, 30, 8, 3), ('B4', 100, 12, 8, 4096, 50, 10, 3)):
+            try:
+                legs[name] = config_leg(torch, name, O_, A_, K_, N_, H_, dev, steps=st_, warmup=wu_)
+            except Exception as e:
+                legs[name] = {'error': str(e)[:300]}
+        try:
+            legs['B5_rank'] = b5_leg(torch, None, pb, 1, 0, dev, False, steps=10, warmup=3, rehearse_world=8, ctl_dev=ctl_dev)
+        except Exception as e:
+            legs['B5_rank'] = {'error': str(e)[:300]}
+        legs.update(policy_legs(torch, dev))          # the reference's default policy and shipped shapes, and the headline shape on SafeCemMpc
+        pre['configs'] = legs
+    if G == 1 and not distributed and not args.no_split_leg:
+        try:
+            pre['split_bf16x3'] = split_leg(torch, pb, dev, steps=min(args.steps, 50), warmup=min(max(args.warmup, 3), 10), n_per_gpu=args.n_per_gpu)
+        except Exception as e:                             # an extra must never cost the run its headline line
+            pre['split_bf16x3'] = {'error': str(e)[:300]}
+    if distributed and not args.no_local_leg:
+        # Multi-rank runs: every rank first plans B2 ALONE on its GPU (a single-rank handle, no collective anywhere: nothing to block in) — the
+        # per-GPU rate of the node's GPUs side by side (a slow or throttled GPU shows here, not as a mystery in the sharded number), and the
+        # same clock conditioning the single-GPU run gets from its extras, so that the N = 1 and N > 1 lines of a scaling sweep compare like
+        # with like.  The rates travel over the control group in one all-gather.
+        lcfg = PlannerConfig(obs_dim=obs, act_dim=act, ensemble_size=K, particles=K, n_samples=2000, horizon=H, n_elite=200, iterations=I,
+                             scorer=pb['scorer'], act_low=pb['low'], act_high=pb['high'], stddev_threshold=-1.0, noise_stddev=1e-3, variant='cem', use_graph=True)
+        lpl = CemPlanner(lcfg, device=dev)
+        lpl.set_weights(pb['weights']); lpl.set_normaliser(pb['inputs_min'], pb['inputs_max'])
+        for i in range(15):
+            lpl.plan(pb['state'], seed=2031, call=i)
+        torch.cuda.synchronize()
+        tl = time.perf_counter()
+        for i in range(40):
+            lpl.plan(pb['state'], seed=2031, call=15 + i)
+        torch.cuda.synchronize()
+        mine = torch.tensor([40.0 / (time.perf_counter() - tl)], dtype=torch.float64, device=ctl_dev)
+        lpl.close()
+        allr = [torch.zeros_like(mine) for _ in range(G)]
+        dist.all_gather(allr, mine)
+        pre['per_rank_single_gpu_b2_plans_per_s'] = [round(float(x.item()), 2) for x in allr]
+    pre['order'] = ('the other legs first (single-GPU: configs, split leg; multi-rank: every rank planning B2 alone), then W warm-up + K timed headline plans at the sustained clock'
+                    if len(pre) else 'headline first (no other leg in front of it in this run): the first timed plans of a cold GPU run during its clock ramp')
 
     for i in range(args.warmup):
         one_plan(i)
@@ -635,26 +684,7 @@ def main():
             if not args.no_split_leg:                  # the same sharded plan on the opt-in split-product rollout: a labelled extra, never `value`
                 out['b5_split_bf16x3'] = b5_leg(torch, dist, pb, G, rank, dev, native, steps=min(args.steps, 20), warmup=min(max(args.warmup, 2), 5),
                                                 rehearse_world=rehearse if G == 1 else 0, ctl_dev=ctl_dev, precision='bf16x3')
-    if G == 1 and not distributed and not args.no_configs:
-        # the other single-GPU BASELINE configs (and one rank of B5's eight) on the driver's line: labelled extras, `value` stays B2
-        pl.close()
-        legs = {}
-        for name, O_, A_, K_, N_, H_, st_, wu_ in (('B1', 60, 2, 5, 500, 25, 60, 15), ('B3', 60, 2, 16, 8192, 30, 8, 3), ('B4', 100, 12, 8, 4096, 50, 10, 3)):
-            try:
-                legs[name] = config_leg(torch, name, O_, A_, K_, N_, H_, dev, steps=st_, warmup=wu_)
-            except Exception as e:
-                legs[name] = {'error': str(e)[:300]}
-        try:
-            legs['B5_rank'] = b5_leg(torch, None, pb, 1, 0, dev, False, steps=10, warmup=3, rehearse_world=8, ctl_dev=ctl_dev)
-        except Exception as e:
-            legs['B5_rank'] = {'error': str(e)[:300]}
-        legs.update(policy_legs(torch, dev))          # the reference's default policy and shipped shapes, and the headline shape on SafeCemMpc
-        out['configs'] = legs
-    if G == 1 and not distributed and not args.no_split_leg:
-        try:
-            out['split_bf16x3'] = split_leg(torch, pb, dev, steps=min(args.steps, 50), warmup=min(max(args.warmup, 3), 10), n_per_gpu=args.n_per_gpu)
-        except Exception as e:                             # an extra must never cost the run its headline line
-            out['split_bf16x3'] = {'error': str(e)[:300]}
+    out.update(pre)                                    # the single-GPU extras, measured before the headline (see `order`)
     if rank == 0 and G == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     if rank == 0:

@@ -117,6 +117,7 @@ def test_bench_multi_rank_leg_two_ranks_on_one_gpu(fake_rccl):
     assert d['config']['hip_graph'] is True
     # the unscaled rate and the literal metric ("(N=2000 K=5 H=30) at G GPUs": 2000 candidates in total, 1000 per rank) beside the weak-scaled value
     assert abs(d['weak_plans_per_s'] * 2.0 - d['value']) < 1e-6 * d['value'] and d['weak_candidates_per_plan'] == 4000 and 'extras_timed_out' not in d
+    assert len(d['per_rank_single_gpu_b2_plans_per_s']) == 2 and min(d['per_rank_single_gpu_b2_plans_per_s']) > 0 and d['order'].startswith('the other legs first')
     b2s = d['b2_strong']
     assert b2s['n_ranks'] == 2 and b2s['candidates_per_rank'] == 1000 and b2s['scaling'] == 'strong' and b2s['unit'] == 'plans/s' and 'N=2000' in b2s['workload']
     assert b2s['exchange'].startswith('ncclAllGather inside the library') and b2s['hip_graph'] is True and b2s['n_ranks_seen_by_rccl'] == 2 and b2s['plans_per_s'] > 0
