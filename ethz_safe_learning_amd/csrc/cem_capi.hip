@@ -853,9 +853,11 @@ int cem_planner_create(const cem_config_t *cfg, void *workspace, size_t workspac
     // beyond the default 64 KB per workgroup the runtime has to be asked, per device (19 KB of the budget are the kernel's
     // static arrays).  Both variants: the uncached one still keeps the elite list (up to 24576 indices = 96 KB) in dynamic LDS.
     h->sel_dyn_limit = 48 * 1024;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&cem_select_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&cem_select_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             140 * 1024) == hipSuccess &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&cem_select_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&cem_select_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            140 * 1024) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&cem_select_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             140 * 1024) == hipSuccess) h->sel_dyn_limit = 140 * 1024;
     else (void)hipGetLastError();
     {
@@ -1155,7 +1157,7 @@ int enqueue_select(cem_planner *h, int it, bool fold_reduce, bool fold_final = f
     const Dims &d = h->d; const Layout &l = h->lay; char *ws = h->ws;
     SelectParams p{}; p.scores = (const float *)(ws + l.scores_global); p.actions = (const float *)(ws + l.actions);
     p.musig = (float *)(ws + l.musig); p.ctrl = (CtrlBlock *)(ws + l.ctrl); p.elite_idx = (int32_t *)(ws + l.elite);
-    p.N = d.N; p.k = d.k; p.HA = d.H * d.A; p.A = d.A; p.check_done = 1; p.crowded = h->cfg.variant == CEM_VARIANT_SAFE;
+    p.N = d.N; p.k = d.k; p.HA = d.H * d.A; p.A = d.A; p.check_done = 1;
     p.smoothing = h->cfg.smoothing; p.one_minus_smoothing = h->cfg.one_minus_smoothing; p.threshold = h->cfg.stddev_threshold;
     p.stamps = (long long *)(ws + l.stamps) + 64;          // past tile 0's rollout stamps; written by -DCEM_STAMPS builds only
     if (fold_reduce) { p.ret = (const float *)(ws + l.returns); p.P = d.P; p.scores_w = (float *)(ws + l.scores_local); }   // (folds_reduce(): world 1, so local == global)
@@ -1212,8 +1214,10 @@ int enqueue_select(cem_planner *h, int it, bool fold_reduce, bool fold_final = f
             if (folded) *folded = true;
         }
         if (cache) lds += (size_t)CEM_SEL_KWORDS(d.N) * 4;
-        if (cache) hipLaunchKernelGGL(cem_select_kernel<true>, dim3(1), dim3(1024), lds, h->stream, p);
-        else hipLaunchKernelGGL(cem_select_kernel<false>, dim3(1), dim3(1024), lds, h->stream, p);
+        // (SafeCemMpc's scores have a crowd near -100: the instantiation that counts and ranks wave by wave; same results either way)
+        if (cache && h->cfg.variant == CEM_VARIANT_SAFE) hipLaunchKernelGGL((cem_select_kernel<true, true>), dim3(1), dim3(1024), lds, h->stream, p);
+        else if (cache) hipLaunchKernelGGL((cem_select_kernel<true, false>), dim3(1), dim3(1024), lds, h->stream, p);
+        else hipLaunchKernelGGL((cem_select_kernel<false, false>), dim3(1), dim3(1024), lds, h->stream, p);
     }
     HIPCHK(hipGetLastError());
     if (h->timing) hipEventRecord(get_event(h, e0 + 1), h->stream);

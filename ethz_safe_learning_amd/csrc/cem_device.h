@@ -1293,7 +1293,6 @@ struct SelectParams {
     float *result; uint32_t *result_dev; const float *eps_out; float noise_stddev;
     int32_t is_last;             // this is the plan's last iteration: with `result`, the completion marker (result[36] = ctrl->seq) follows the result
     int32_t N, k, HA, A, check_done;
-    int32_t crowded;             // the scores have a crowd (SafeCemMpc: the unsafe candidates near -100): count buckets wave by wave (a speed hint only)
     float smoothing, one_minus_smoothing, threshold;   // one_minus_smoothing = fl32(1.0 - smoothing) rounded once, as cem_mpc.py:64-65 does
     long long *stamps;           // [8] section stamps of -DCEM_STAMPS diagnostic builds
 };
@@ -1386,7 +1385,10 @@ __device__ __forceinline__ void cem_ms_find(const uint32_t *h, const int nbins, 
 // One CU, so the kernel is a latency chain: the scores are staged in LDS once (CACHE; they are read by 4 radix passes, the
 // compaction and the best-of-elite), the 256-bin suffix scan of a pass is done by one wave with shuffles (2 barriers per
 // pass), gathers are issued in batches, and the two serial tails run on different waves.  All sums keep a fixed order.
-template <bool CACHE>
+// CROWDED: the scores have a crowd — SafeCemMpc, where most candidates are unsafe and sit near -100 (the host picks the instantiation by the
+// objective; a speed choice only: both give the same result on any scores).  It is a template parameter because the extra paths, though never
+// taken on CemMpc's spread-out scores, cost that case 0.5 us through code layout and register allocation alone (round 5, scripts/stamp_select.py).
+template <bool CACHE, bool CROWDED = false>
 __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char sel_smem[];
@@ -1490,10 +1492,10 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
             h2k[tid] = 0u; h2k[tid + 1024] = 0u;
             if (tid == 0) sh_cnt = 0u;
             __syncthreads();
-            if (p.crowded) {
+            if (CROWDED) {
                 // SafeCemMpc: most candidates are unsafe and their scores — return minus 100 — share ONE bucket.  Whole waves enter and the bucket
                 // of a wave's first key is added once for all the lanes that share it (one round: -0.7 us at B2; a second round gains nothing,
-                // and on CemMpc's spread-out scores the round costs 0.4 us for nothing: hence the flag, which the host sets by the objective)
+                // and on CemMpc's spread-out scores the round costs 0.4 us for nothing)
                 for (int i0 = 0; i0 < N; i0 += 1024) {
                     const int i = i0 + tid;
                     const uint32_t off = i < N ? ckey[CEM_SEL_KIDX(i)] - base : 0xFFFFFFFFu;
@@ -1520,7 +1522,7 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
             cem_ms_find<false>(h2k, 2048, need, sh20, bucket, need1);   // ge[bucket] >= need > ge[bucket + 1]; need1 = need - ge[bucket + 1]
             const uint32_t m = h2k[bucket];
             if (sh == 0) { prefix = base + bucket; need = need1; solved = true; break; }     // the bucket is ONE key: `need1` of its ties are taken
-            if (m <= 32u) {                                              // (workgroup-uniform) a handful of keys — the usual CemMpc case: m threads rank them, one barrier fewer
+            if (m <= (CROWDED ? 32u : 256u)) {                           // (workgroup-uniform) a handful of keys — the usual CemMpc case: m threads rank them, one barrier fewer
                 for (int i = tid; i < N; i += 1024) {
                     const uint32_t key = ckey[CEM_SEL_KIDX(i)], off = key - base;
                     if (off <= window && (off >> sh) == bucket) { const uint32_t pos = atomicAdd(&sh_cnt, 1u); lkey[pos] = key; lidx[pos] = (uint32_t)i; }
@@ -1536,7 +1538,7 @@ __global__ __launch_bounds__(1024) void cem_select_kernel(const SelectParams p)
                 prefix = sh_prefix; need = sh_need; solved = true;
                 break;
             }
-            if (m <= 256u) {
+            if (CROWDED && m <= 256u) {
                 // Collect the bucket's keys (a wave takes its slots with ONE returning atomic, lanes place themselves behind it), then rank
                 // them against each other with the whole workgroup: key j is compared with a quarter of the list by each of four threads and the
                 // partial counts meet in LDS (integers: order-free).  Round 5: with `m` threads walking all m keys alone, a SafeCemMpc

@@ -21,6 +21,7 @@ for N in [int(a) for a in sys.argv[1:]] or [2000, 16000]:
         for it in range(5):
             pl.plan_rollout(it); pl.plan_select(it)
             if i >= 2:                                       # every select of the later plans: one launch's stamps are +-0.5 us
+                pl.stream.synchronize()
                 acc.append(pl._view(pl.layout.stamps + 64 * 8, 8, torch.int64).cpu().numpy().astype(np.float64))
         pl.plan_end()
     st = np.mean(np.stack([a - a[0] for a in acc]), axis=0)
