@@ -922,6 +922,34 @@ def test_compute_objective_op_matches_oracle(case, variant):
     # a horizon other than the handle's and numpy in / numpy out through the policy-level wrapper are covered in test_simba_api
 
 
+@pytest.mark.parametrize('H,P,E,n', [(1, 5, 5, 16), (7, 3, 3, 70), (8, 45, 15, 10), (15, 33, 3, 8), (16, 5, 5, 64), (17, 9, 3, 24), (32, 17, 1, 20), (40, 16, 4, 130)])
+def test_reduce_kernel_shapes(H, P, E, n):
+    """cem_reduce_kernel (particle mean + per-step Beta filter, safe_cem_mpc.py:90-96,110-120) over the shapes its round-5 form
+    distinguishes: horizons below 16 (the sixteen waves share out (step, particle slice) pairs: 16 / H waves per step, partial counts
+    added in LDS), of 16 and more (two steps' loads per trip), particle counts beyond one batch of loads (> 8 resp. > 16 per wave),
+    candidates that do not fill a 64-lane block — through cem_compute_objective on RANDOM trajectories (lidar bins uniform in [0, 1]:
+    about half the (row, step) pairs hit a hazard, goals are reached at random steps), against the oracle on the same tensor."""
+    torch = _torch()
+    pb = hp.make_problem(seed=33, E=E)
+    for variant in ('safe', 'cem'):
+        ocfg, pcfg = hp.configs(pb, N=n, H=H, P=P, E=E, k=max(1, n // 4), I=1, variant=variant, post=0.3)
+        pl = hp.make_planner(pb, pcfg)
+        rng = np.random.default_rng(1000 * H + P)
+        traj = rng.uniform(0.0, 1.0, (P * n, H + 1, 60)).astype(np.float32)
+        traj[:, :, 3:19] = rng.uniform(0.055, 0.5, (P * n, H + 1, 16)).astype(np.float32)     # goal lidar: one row-step in six is within the goal radius
+        lo = np.tile(np.linspace(0.0, 0.12, n), P)[:, None, None]                             # hazard lidar: candidate j's bins are uniform in [lo_j, 1] —
+        traj[:, :, 22:38] = (lo + (1.0 - lo) * rng.uniform(0.0, 1.0, (P * n, H + 1, 16))).astype(np.float32)   # the first candidates hit hazards often, the last never
+        got = pl.compute_objective(traj).cpu().numpy()
+        t64 = traj.astype(np.float64)
+        ref = o.compute_objective_safe(t64, P, n, pb['scorer'], 0.3) if variant == 'safe' else o.compute_objective_cem(t64, P, n, pb['scorer'])
+        ok = o.threshold_margins(t64, pb['scorer']).reshape(P, n).min(axis=0) > 1e-5
+        assert ok.mean() > 0.5
+        assert _score_err(got[ok], ref[ok]) <= 1.0, (variant, np.abs(got[ok] - ref[ok]).max())
+        if variant == 'safe':
+            assert 0 < (ref < -50).sum() < n, 'both safe and unsafe candidates should occur (%d unsafe of %d)' % ((ref < -50).sum(), n)
+        pl.close()
+
+
 def test_scorer_ops_match_oracle():
     """cem_scorer_reward / cem_scorer_cost = env.get_reward / get_cost (safety_gym.py:62-66,110-166) on arbitrary observation
     batches: rewards to fp32 rounding, goal flags and costs exactly (rows within 1e-5 of a threshold excluded)."""
