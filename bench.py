@@ -263,6 +263,35 @@ class HeadlineGuard:
         return False
 
 
+class RunGuard:
+    """A multi-rank run whose HEADLINE blocks — a rank died, a collective (captured or not) never completes: nothing in-process can recover
+    from that, and the launcher would only see its own timeout and no line at all.  Armed before the first collective of a distributed run: if
+    the line has not been printed within `seconds`, rank 0 prints a line that SAYS so (`value` null, an `error`, what had been reached) and
+    every rank leaves with a non-zero status.  Disarmed once the headline is measured (the extras have their own guard)."""
+
+    def __init__(self, rank, gpus, seconds):
+        import threading
+        self.rank, self.gpus, self.seconds, self.stage = rank, gpus, seconds, 'set-up'
+        self.timer = threading.Timer(seconds, self.fire)
+        self.timer.daemon = True
+
+    def fire(self):
+        sys.stderr.write('bench.py rank %d: the headline did not finish within %d s (reached: %s): a rank is blocked in a collective or the GPU hangs\n'
+                         % (self.rank, self.seconds, self.stage))
+        sys.stderr.flush()
+        if self.rank == 0:
+            print(json.dumps({'metric': 'planning steps/sec (CEM-MPC, N=2000 K=5 H=30)', 'value': None, 'unit': 'plans/s', 'n_gpus': self.gpus,
+                              'error': 'the headline did not finish within %d s (reached: %s)' % (self.seconds, self.stage), 'headline_timed_out': True}), flush=True)
+        os._exit(4)
+
+    def start(self):
+        self.timer.start()
+        return self
+
+    def cancel(self):
+        self.timer.cancel()
+
+
 def config_leg(torch, name, obs, act, K, N, H, dev, steps, warmup, P=None, I=5, k=None, variant='cem', thr=-1.0, post=0.15, noise=1e-3, what=None):
     """One more configuration on the same line as the headline: whole plans timed like the headline (graph replay), then the launches
     of an iteration by HIP events on the planner's stream.  Labelled extras — `value` stays B2.  The BASELINE configs (configs[0], [2],
@@ -462,6 +491,7 @@ def main():
     ap.add_argument('--no-b5', action='store_true', help='skip the B5 extras of a multi-GPU run')
     ap.add_argument('--no-local-leg', action='store_true', help='multi-rank runs: skip the per-rank single-GPU B2 leg in front of the headline')
     ap.add_argument('--extras-timeout', type=int, default=240, help='seconds after which a multi-rank run prints its headline without the extras')
+    ap.add_argument('--headline-timeout', type=int, default=420, help='multi-rank runs: seconds after which a run without a headline prints an error line and exits non-zero')
     ap.add_argument('--extras-timeout-status', type=int, default=0, help='exit status of a run whose extras timed out (the line then carries "extras_timed_out": true)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--chunks', type=int, default=0)
@@ -483,9 +513,11 @@ def main():
     # CEM_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box, tests/test_gpu_multirank.py): every rank uses cuda:0, gloo carries the
     # barrier / max-over-ranks (RCCL refuses two ranks on one device) and CEM_RCCL_LIBRARY names the stand-in for the collective
     share_gpu = os.environ.get('CEM_BENCH_SHARE_GPU') == '1'
+    run_guard = None
     if distributed:
         assert world == G, 'launch with torch.distributed.run --nproc-per-node %d' % G
         import torch.distributed as dist
+        run_guard = RunGuard(rank, G, args.headline_timeout).start()
         if share_gpu:
             torch.cuda.set_device(0)
             dist.init_process_group('gloo')
@@ -561,6 +593,8 @@ def main():
             pre['split_bf16x3'] = split_leg(torch, pb, dev, steps=min(args.steps, 50), warmup=min(max(args.warmup, 3), 10), n_per_gpu=args.n_per_gpu)
         except Exception as e:                             # an extra must never cost the run its headline line
             pre['split_bf16x3'] = {'error': str(e)[:300]}
+    if run_guard:
+        run_guard.stage = 'per-rank single-GPU leg'
     if distributed and not args.no_local_leg:
         # Multi-rank runs: every rank first plans B2 ALONE on its GPU (a single-rank handle, no collective anywhere: nothing to block in) — the
         # per-GPU rate of the node's GPUs side by side (a slow or throttled GPU shows here, not as a mystery in the sharded number), and the
@@ -585,11 +619,15 @@ def main():
     pre['order'] = ('the other legs first (single-GPU: configs, split leg; multi-rank: every rank planning B2 alone), then W warm-up + K timed headline plans at the sustained clock'
                     if len(pre) else 'headline first (no other leg in front of it in this run): the first timed plans of a cold GPU run during its clock ramp')
 
+    if run_guard:
+        run_guard.stage = 'headline warm-up'
     for i in range(args.warmup):
         one_plan(i)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    if run_guard:
+        run_guard.stage = 'headline timed steps'
     t0 = time.perf_counter()
     stamps = [t0]
     for i in range(args.steps):
@@ -605,6 +643,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert it == I and np.all(np.isfinite(a))
+    if run_guard:
+        run_guard.stage = 'roofline timing'
 
     # roofline of the dominant kernel: HIP events on the handle's stream around every rollout launch (eager launches)
     pl.set_timing(True)
@@ -641,6 +681,8 @@ def main():
                 # MFMA-pipe utilisation: PMC busy cycles per launch over 1024 SIMDs x this run's launch time
                 mfma_util = prof.get('sq_valu_mfma_busy_cycles_per_launch', 0.0) / (1024 * avg_ms * 1e-3 * SHADER_CLOCK_HZ) or None
 
+    if run_guard:
+        run_guard.cancel()                             # the headline exists: from here on the extras' own guard keeps it
     plans_per_s = args.steps / dt
     b2_equiv = plans_per_s * (N / 2000.0)
     out = {

@@ -15,7 +15,7 @@ from tests.test_gpu_whole_plan import whole_plan_vs_oracle  # noqa: E402
 n_b2 = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 n_b4 = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 cases = [('B2', 60, 2, 5, 2000, 30, 5, 'cem', 200, 1234, n_b2), ('B2', 60, 2, 5, 2000, 30, 5, 'safe', 80, 1234, n_b2),
-         ('B4', 100, 12, 8, 4096, 50, 3, 'cem', 409, 4321, n_b4)]
+         ('B4', 100, 12, 8, 4096, 50, 3, 'cem', 409, 4321, n_b4), ('B3', 60, 2, 16, 8192, 30, 2, 'cem', 819, 4321, n_b4)]
 for name, O, A, K, N, H, I, variant, k, pbs, n_seeds in cases:
     for seed in range(1, n_seeds + 1):
         t0 = time.time()

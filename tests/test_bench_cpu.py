@@ -35,3 +35,26 @@ def test_headline_guard_keeps_the_headline_and_says_so():
     assert r.returncode == 3 and json.loads(r.stdout.strip().splitlines()[-1])['extras_timed_out'] is True
     r = _run(1, 3)                      # the other ranks: no line, the same stderr notice, the same status
     assert r.returncode == 3 and r.stdout.strip() == '' and 'rank 1' in r.stderr
+
+
+CHILD_RUN = r'''
+import sys, time
+sys.path.insert(0, %r)
+import bench
+g = bench.RunGuard(rank=int(sys.argv[1]), gpus=8, seconds=0.3).start()
+g.stage = 'headline warm-up'
+time.sleep(30)              # a collective that never completes
+print('not reached')
+'''
+
+
+def test_run_guard_says_that_the_headline_never_finished():
+    """A multi-rank headline that blocks: rank 0 prints a line with `value` null, an error and how far the run got; every rank leaves
+    with a non-zero status and a stderr line — instead of the launcher's timeout and no line at all."""
+    r = subprocess.run([sys.executable, '-c', CHILD_RUN % ROOT, '0'], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 4 and 'not reached' not in r.stdout
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['value'] is None and line['headline_timed_out'] is True and 'headline warm-up' in line['error'] and line['n_gpus'] == 8
+    assert 'did not finish' in r.stderr
+    r = subprocess.run([sys.executable, '-c', CHILD_RUN % ROOT, '3'], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 4 and r.stdout.strip() == '' and 'rank 3' in r.stderr

@@ -111,6 +111,7 @@ def whole_plan_vs_oracle(name, O, A, K, N, H, I, variant, k, seed, call=3, post=
 # seeds: chosen on MI355X with scripts/scan_whole_plan_seeds.py (the first of 1.. for which no threshold crossing sits on an elite boundary)
 B2_SEEDS = {'cem': 1, 'safe': 1}
 B4_SEED = 1
+B3_SEED = 1
 
 
 @pytest.mark.parametrize('variant', ['cem', 'safe'])
@@ -124,3 +125,9 @@ def test_b4_whole_plan_matches_oracle():
     """BASELINE config B4 (Doggo-scale obs 100 / act 12, K = 8, N = 4096, H = 50; the two-input-block kernel family): 3 iterations at
     full width (the oracle needs ~20 s and 0.65 GB of model noise per iteration)."""
     whole_plan_vs_oracle('B4', 100, 12, 8, 4096, 50, 3, 'cem', 409, seed=B4_SEED, pb_seed=4321)
+
+
+def test_b3_whole_plan_matches_oracle():
+    """BASELINE config B3 (K = P = E = 16 members, N = 8192: 131 072 rows per iteration, the four-chunk tiles with the sampler as a launch of
+    its own): 2 iterations at full width (the oracle needs ~30 s and 0.94 GB of model noise per iteration) — iteration 0 and one refit."""
+    whole_plan_vs_oracle('B3', 60, 2, 16, 8192, 30, 2, 'cem', 819, seed=B3_SEED, pb_seed=4321)
