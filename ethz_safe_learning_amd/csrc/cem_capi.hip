@@ -66,7 +66,7 @@ int validate(const cem_config_t *c)
         c->n_elite < 1 || c->n_elite > c->n_samples || c->world_size < 1 || c->rank < 0 || c->rank >= c->world_size)
         return CEM_ERR_INVALID_ARG;
     if (c->units < 1) return CEM_ERR_INVALID_ARG;
-    if (c->activation < CEM_ACT_RELU || c->activation > CEM_ACT_SELU) return CEM_ERR_INVALID_ARG;
+    if (c->activation < CEM_ACT_RELU || c->activation > CEM_ACT_GELU) return CEM_ERR_INVALID_ARG;
     if (!(fabs((double)c->one_minus_smoothing - (1.0 - (double)c->smoothing)) <= 2e-7)) return CEM_ERR_INVALID_ARG;   // see cem_mpc.h
     if (c->units > CEM_WIDE_U) return CEM_ERR_UNSUPPORTED;  // <= 128: the fast kernel (narrower layers run zero-padded, exactly); 129..256: cem_rollout_wide.h
     if (c->obs_dim + c->act_dim > CEM_U) return CEM_ERR_UNSUPPORTED;
@@ -1701,7 +1701,7 @@ int validate_train(const cem_train_config_t *c)
 {
     if (!c || c->abi_version != CEM_ABI_VERSION) return CEM_ERR_INVALID_ARG;
     if (c->inputs_dim < 1 || c->outputs_dim < 1 || c->n_layers < 1 || c->ensemble_size < 1 || c->batch_size < 1) return CEM_ERR_INVALID_ARG;
-    if (c->units < 1 || c->activation < CEM_ACT_RELU || c->activation > CEM_ACT_SELU) return CEM_ERR_INVALID_ARG;
+    if (c->units < 1 || c->activation < CEM_ACT_RELU || c->activation > CEM_ACT_GELU) return CEM_ERR_INVALID_ARG;
     if (!(c->dropout_rate >= 0.f && c->dropout_rate < 1.f)) return CEM_ERR_INVALID_ARG;
     if (c->units > CEM_TWIDE || c->inputs_dim > CEM_U || c->outputs_dim > CEM_U || c->batch_size > CEM_TB) return CEM_ERR_UNSUPPORTED;
     return CEM_OK;
@@ -1715,7 +1715,9 @@ void train_layout(cem_trainer *t)
 {
     const cem_train_config_t &c = t->cfg;
     t->nat = train_nat(&c);
-    t->scratch_pm = (size_t)(c.n_layers + 8) * CEM_TROWS * (c.units > CEM_TS ? CEM_TWIDE : CEM_TS);       // per (member, row part) workgroup
+    // per (member, row part) workgroup: the input, L hidden outputs, seven head / loss / gradient matrices — and, for swish / gelu, the L kept
+    // pre-activations the backward gate of a non-monotone activation needs (cem_train.h: GemmEpi::outz)
+    t->scratch_pm = (size_t)(c.n_layers + 8 + (CEM_ACT_NEEDS_Z(c.activation) ? c.n_layers : 0)) * CEM_TROWS * (c.units > CEM_TS ? CEM_TWIDE : CEM_TS);
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align256(o + bytes); return r; };
     t->oW = take(t->nat * c.ensemble_size * 4); t->oM = take(t->nat * c.ensemble_size * 4); t->oV = take(t->nat * c.ensemble_size * 4);

@@ -257,8 +257,18 @@ __device__ __forceinline__ float cem_activation_fwd(const int a, const float v)
     case 4: return v > 0.f ? v : 0.2f * v;
     case 5: return cem_softplus(v);
     case 6: return v > 0.f ? 1.0507009873554805f * v : 1.7580993408473766f * expm1f(v);     // tf.nn.selu: scale * (z or alpha * (e^z - 1)); scale * alpha = 1.7580993
+    case 7: return v / (1.0f + expf(-v));                                                     // tf.nn.swish = tf.nn.silu: z * sigmoid(z)
+    case 8: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));                        // tf.nn.gelu (approximate=False, its default): z * Phi(z)
     default: return fmaxf(v, 0.f);
     }
+}
+// swish and gelu are not monotone: their derivative is NOT a function of the layer's output.  The trainer keeps these layers' PRE-activations
+// (cem_train.h: GemmEpi::outz) and gates with f'(z):  swish' = s + z s (1 - s), s = sigmoid(z);  gelu' = Phi(z) + z phi(z).
+#define CEM_ACT_NEEDS_Z(a) ((a) >= 7)
+__device__ __forceinline__ float cem_activation_gate_z(const int a, const float d, const float z)
+{
+    if (a == 7) { const float sg = 1.0f / (1.0f + expf(-z)); return d * (sg + z * sg * (1.0f - sg)); }
+    return d * (0.5f * (1.0f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * expf(-0.5f * z * z));
 }
 __device__ __forceinline__ float cem_activation_gate(const int a, const float d, const float h)     // d * f'(z), given h = f(z)
 {

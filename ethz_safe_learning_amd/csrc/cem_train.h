@@ -77,7 +77,8 @@ typedef __attribute__((address_space(1))) float *gptr;              // function 
 struct GemmEpi {
     gptr out; int ldo;
     gcptr bias;            // [N] or null
-    gcptr gate; int ldg;   // [M][ldg] or null: v = v * f'(z) with gate = f(z), the gated layer's output
+    gcptr gate; int ldg;   // [M][ldg] or null: v = v * f'(z) with gate = f(z), the gated layer's output — or, for swish / gelu (CEM_ACT_NEEDS_Z),
+                           // the layer's kept PRE-activation z (GemmEpi::outz of its forward GEMM; a unit Dropout dropped holds CEM_Z_DROPPED)
     int relu;              // 0: none; 1 + enum cem_activation: the hidden layers' nonlinearity (forward) / the one whose derivative gates (backward)
     // optional column split (the mu | variance head pair as ONE GEMM): columns n >= nsplit go to out1 / bias1 at n - nsplit
     gptr out1; gcptr bias1;
@@ -92,6 +93,9 @@ struct GemmEpi {
     float drop_scale, drop_keep;           // 1 / (1 - rate), 1 - rate
     uint32_t drop_step, drop_c2, drop_member, drop_k0, drop_k1;
     int drop_row0;
+    // optional (forward GEMMs of swish / gelu layers): the pre-activation z of every output element, same indexing as `out` — what the
+    // backward gate of a non-monotone activation needs; an element Dropout drops is stored as CEM_Z_DROPPED (a NaN bit pattern, compared as bits)
+    gptr outz;
 };
 
 __device__ __forceinline__ float cem_dropout_fwd(const GemmEpi &e, const int row, const int n, const float v)
@@ -101,9 +105,15 @@ __device__ __forceinline__ float cem_dropout_fwd(const GemmEpi &e, const int row
     const uint32_t wsel = (n & 3) == 0 ? c0 : ((n & 3) == 1 ? c1 : ((n & 3) == 2 ? c2 : c3));
     return wsel >= e.drop_thresh ? v * e.drop_scale : 0.f;
 }
-// d * (d output / d pre-activation) of a hidden layer given its STORED output h (after activation and dropout)
+#define CEM_Z_DROPPED 0xFFC00001u
+// d * (d output / d pre-activation) of a hidden layer given its STORED output h (after activation and dropout) — or its kept pre-activation
 __device__ __forceinline__ float cem_layer_gate(const GemmEpi &e, const float d, const float h)
 {
+    if (e.relu > 1 && CEM_ACT_NEEDS_Z(e.relu - 1)) {                  // swish / gelu: `h` is z (or the dropped marker)
+        if (__float_as_uint(h) == CEM_Z_DROPPED) return 0.f;
+        const float g = cem_activation_gate_z(e.relu - 1, d, h);
+        return e.drop_thresh ? g * e.drop_scale : g;
+    }
     if (e.drop_thresh == 0u) return e.relu <= 1 ? (h > 0.f ? d : 0.f) : cem_activation_gate(e.relu - 1, d, h);
     if (h == 0.f) return 0.f;                                  // dropped (or a kink / zero of f: a set of measure zero)
     return cem_activation_gate(e.relu - 1, d, h * e.drop_keep) * e.drop_scale;
@@ -255,8 +265,11 @@ __device__ __attribute__((noinline)) void wg_gemm_t(const int M, const int N, co
                         if (e.bias) v = v + bia[jn];
                         if (e.gate) v = cem_layer_gate(e, v, gat[rk][i][jn]);
                         else if (e.relu) {
+                            const float zpre = v;
                             v = e.relu == 1 ? fmaxf(v, 0.f) : cem_activation_fwd(e.relu - 1, v);
-                            if (e.drop_thresh) v = cem_dropout_fwd(e, mI, n, v);
+                            bool dropped = false;
+                            if (e.drop_thresh) { const float kept = cem_dropout_fwd(e, mI, n, 1.0f); dropped = kept == 0.f; v = dropped ? 0.f : v * e.drop_scale; }
+                            if (e.outz && mI < M && n < N) e.outz[mI * e.ldo + n] = dropped ? __uint_as_float(CEM_Z_DROPPED) : zpre;
                         }
                         if (mI < M && n < N) (n < sp.nsplit ? e.out : e.out1)[(mI < M ? mI : M - 1) * e.ldo + (n < sp.nsplit ? n : n - sp.nsplit)] = v;
                     }
@@ -381,8 +394,11 @@ __device__ __attribute__((noinline)) void wg_gemm_r16_deep(const int M, const in
         if (e.bias) v = v + bia;
         if (e.gate) v = cem_layer_gate(e, v, gat[i]);
         else if (e.relu) {
+            const float zpre = v;
             v = e.relu == 1 ? fmaxf(v, 0.f) : cem_activation_fwd(e.relu - 1, v);
-            if (e.drop_thresh) v = cem_dropout_fwd(e, mI, n, v);
+            bool dropped = false;
+            if (e.drop_thresh) { const float kept = cem_dropout_fwd(e, mI, n, 1.0f); dropped = kept == 0.f; v = dropped ? 0.f : v * e.drop_scale; }
+            if (e.outz && mI < M && n < N) e.outz[mI * e.ldo + n] = dropped ? __uint_as_float(CEM_Z_DROPPED) : zpre;
         }
         if (mI < M && n < N) (n < sp.nsplit ? e.out : e.out1)[mI * e.ldo + (n < sp.nsplit ? n : n - sp.nsplit)] = v;
     }
@@ -463,6 +479,7 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
     float *dv = dmu + CEM_TROWS * S;
     float *dha = dv + CEM_TROWS * S;
     float *dhb = dha + CEM_TROWS * S;
+    float *zs = CEM_ACT_NEEDS_Z(p.act) ? dhb + CEM_TROWS * S : nullptr;      // [L][TROWS][S] pre-activations of swish / gelu layers (the host sizes the scratch for them)
     // natural-blob offsets (cem_mpc.h): W_0,b_0,...,W_mu,b_mu,W_var,b_var
     auto offW = [&](int l) { return l == 0 ? (size_t)0 : (size_t)D * U + U + (size_t)(l - 1) * ((size_t)U * U + U); };
     auto offb = [&](int l) { return offW(l) + (size_t)(l == 0 ? D : U) * U; };
@@ -496,6 +513,7 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
             fe.drop_thresh = p.drop_thresh; fe.drop_scale = p.drop_scale; fe.drop_keep = p.drop_keep; fe.drop_step = p.drop_step;
             fe.drop_c2 = ((uint32_t)l << 8) | (3u << 16); fe.drop_member = (uint32_t)m; fe.drop_k0 = p.drop_k0; fe.drop_k1 = p.drop_k1; fe.drop_row0 = row0;
         }
+        if (zs && p.train) fe.outz = (gptr)(zs + (size_t)l * CEM_TROWS * S);
         wg_gemm(Bt, U, l == 0 ? D : U, (gcptr)hin, S, 1, (gcptr)Wl, U, 1, fe, CEM_NOSPLIT);
     }
     CEM_TR_STAMP(2);
@@ -538,7 +556,7 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
     // dh_L = (dmu Wmu^T + dv Wvar^T) * relu'(h_L): the relu mask rides in the epilogue of the GEMM that completes dh
     // dh_L = ([dmu | dv] [W_mu | W_var]^T) * relu'(h_L): one GEMM over K = 2O; the relu mask rides in its epilogue
     wg_gemm(Bt, U, 2 * O, (gcptr)dmu, S, 1, (gcptr)(W + oWmu), 1, O,
-            GemmEpi{(gptr)dha, S, nullptr, (gcptr)hL, S, 1 + p.act, nullptr, nullptr, p.stamps, nullptr, nullptr, p.drop_thresh, p.drop_scale, p.drop_keep}, GemmSplit{(gcptr)dv, (gcptr)(W + oWv), O, 0x7fffffff});
+            GemmEpi{(gptr)dha, S, nullptr, (gcptr)(zs ? zs + (size_t)(L - 1) * CEM_TROWS * S : hL), S, 1 + p.act, nullptr, nullptr, p.stamps, nullptr, nullptr, p.drop_thresh, p.drop_scale, p.drop_keep}, GemmSplit{(gcptr)dv, (gcptr)(W + oWv), O, 0x7fffffff});
     CEM_TR_STAMP(6);
     float *dcur = dha, *dnext = dhb;
     for (int l = L - 1; l >= 0; --l) {
@@ -546,7 +564,7 @@ __global__ __launch_bounds__(CEM_TNT) void cem_train_step_kernel(const TrainPara
         const int in = l == 0 ? D : U;
         wg_gemm(in, U, Bt, (gcptr)hin, 1, S, (gcptr)dcur, S, 1, GemmEpi{(gptr)(G + offW(l)), U, nullptr, nullptr, 0, 0, nullptr, nullptr, p.stamps, (gptr)(G + offb(l)), nullptr}, CEM_NOSPLIT);   // dW_l = h_{l-1}^T dh_l, db_l = column sums of dh_l
         if (l > 0) {
-            wg_gemm(Bt, U, U, (gcptr)dcur, S, 1, (gcptr)(W + offW(l)), 1, U, GemmEpi{(gptr)dnext, S, nullptr, (gcptr)hin, S, 1 + p.act, nullptr, nullptr, p.stamps, nullptr, nullptr, p.drop_thresh, p.drop_scale, p.drop_keep}, CEM_NOSPLIT);   // dh_{l-1} = (dh_l W_l^T) relu'
+            wg_gemm(Bt, U, U, (gcptr)dcur, S, 1, (gcptr)(W + offW(l)), 1, U, GemmEpi{(gptr)dnext, S, nullptr, (gcptr)(zs ? zs + (size_t)(l - 1) * CEM_TROWS * S : hin), S, 1 + p.act, nullptr, nullptr, p.stamps, nullptr, nullptr, p.drop_thresh, p.drop_scale, p.drop_keep}, CEM_NOSPLIT);   // dh_{l-1} = (dh_l W_l^T) f'(z_{l-1})
             float *t = dcur; dcur = dnext; dnext = t;
         }
     }

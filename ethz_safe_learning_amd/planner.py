@@ -48,7 +48,7 @@ class PlannerConfig:
     act_high: Sequence[float]
     units: int = 128
     n_layers: int = 4
-    activation: str = 'relu'           # mlp_params['activation'] (config/models.yaml:12): relu | tanh | sigmoid | elu | leaky_relu | softplus | selu (see ACTIVATIONS)
+    activation: str = 'relu'           # mlp_params['activation'] (config/models.yaml:12): relu | tanh | sigmoid | elu | leaky_relu | softplus | selu | swish | gelu (see ACTIVATIONS)
     smoothing: float = 0.0
     stddev_threshold: float = -1.0
     noise_stddev: float = 0.0
@@ -66,13 +66,13 @@ class PlannerConfig:
 
 
 # mlp_params['activation'] is a string the reference `eval`s (mlp_ensemble.py:14): the TensorFlow names that map onto enum cem_activation
-ACTIVATIONS = {'relu': 0, 'tanh': 1, 'sigmoid': 2, 'elu': 3, 'leaky_relu': 4, 'softplus': 5, 'selu': 6}
+ACTIVATIONS = {'relu': 0, 'tanh': 1, 'sigmoid': 2, 'elu': 3, 'leaky_relu': 4, 'softplus': 5, 'selu': 6, 'swish': 7, 'silu': 7, 'gelu': 8}
 
 
 def activation_code(name) -> int:
-    """'tf.nn.relu' / 'tf.nn.tanh' / 'tf.math.tanh' / 'tf.keras.activations.elu' / 'relu' ... -> enum cem_activation.  Raises
-    for anything else (swish / gelu need the pre-activation in the backward pass, which the device trainer does not keep: their derivative is
-    not a function of the layer's output)."""
+    """'tf.nn.relu' / 'tf.nn.tanh' / 'tf.math.tanh' / 'tf.keras.activations.elu' / 'tf.nn.swish' / 'relu' ... -> enum cem_activation.  Raises
+    for anything else.  (swish / silu and gelu are not monotone — their derivative is not a function of the layer's output — so the
+    device trainer keeps the pre-activations of those layers; gelu is TensorFlow's default exact form, approximate=False.)"""
     key = str(name).strip().split('.')[-1].lower()
     if key not in ACTIVATIONS:
         raise NotImplementedError("activation %r is not built (supported: %s — as bare names or with a tf.nn. / tf.math. / "

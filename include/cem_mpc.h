@@ -64,9 +64,11 @@ enum cem_variant { CEM_VARIANT_CEM = 0 /* CemMpc */, CEM_VARIANT_SAFE = 1 /* Saf
 
 /* mlp_params['activation'] of config/models.yaml:12, which the reference `eval`s (mlp_ensemble.py:14): the hidden layers'
  * nonlinearity.  relu (the shipped value) runs on the tuned kernels; the others on the generic rollout kernel and the
- * GEMM-by-GEMM trainer.  tf.nn.elu: alpha 1; tf.nn.leaky_relu: alpha 0.2; tf.nn.selu: scale 1.0507..., alpha 1.6732... (TensorFlow's
- * defaults).  All of these have derivatives that are functions of the layer's OUTPUT, which is what the trainer keeps; swish / gelu do not. */
-enum cem_activation { CEM_ACT_RELU = 0, CEM_ACT_TANH = 1, CEM_ACT_SIGMOID = 2, CEM_ACT_ELU = 3, CEM_ACT_LEAKY_RELU = 4, CEM_ACT_SOFTPLUS = 5, CEM_ACT_SELU = 6 };
+ * GEMM-by-GEMM trainer.  tf.nn.elu: alpha 1; tf.nn.leaky_relu: alpha 0.2; tf.nn.selu: scale 1.0507..., alpha 1.6732...; tf.nn.swish (= silu):
+ * z sigmoid(z); tf.nn.gelu: the exact form z Phi(z) (approximate=False) — TensorFlow's defaults.  Up to selu the derivative is a function
+ * of the layer's OUTPUT, which is what the trainer keeps; swish / gelu are not monotone, so for them the trainer keeps the pre-activations too. */
+enum cem_activation { CEM_ACT_RELU = 0, CEM_ACT_TANH = 1, CEM_ACT_SIGMOID = 2, CEM_ACT_ELU = 3, CEM_ACT_LEAKY_RELU = 4, CEM_ACT_SOFTPLUS = 5, CEM_ACT_SELU = 6,
+                      CEM_ACT_SWISH = 7, CEM_ACT_GELU = 8 };
 
 /* SafetyGymStateScorer fields used by the 'goal' task (safety_gym.py:104-176).
  * The constants come from safety_gym's Engine config (absent from the

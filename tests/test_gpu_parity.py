@@ -1168,7 +1168,7 @@ def test_device_result_block_mirrors_the_host_result():
 
 
 @pytest.mark.parametrize('units', [128, 40])
-@pytest.mark.parametrize('activation', ['tf.nn.tanh', 'tf.nn.sigmoid', 'tf.nn.elu', 'tf.nn.leaky_relu', 'tf.nn.softplus', 'tf.nn.selu'])
+@pytest.mark.parametrize('activation', ['tf.nn.tanh', 'tf.nn.sigmoid', 'tf.nn.elu', 'tf.nn.leaky_relu', 'tf.nn.softplus', 'tf.nn.selu', 'tf.nn.swish', 'tf.nn.gelu'])
 def test_other_activations_match_oracle(activation, units):
     """mlp_params['activation'] other than relu (config/models.yaml:12 takes any TensorFlow activation; the reference evals the
     string, mlp_ensemble.py:14,20): the generic rollout kernel applies it in the hidden layers — per-candidate scores against the

@@ -173,7 +173,7 @@ def test_validation_loss_over_many_chunks(kernel, monkeypatch):
     tr.close()
 
 
-@pytest.mark.parametrize('activation', ['tf.nn.tanh', 'tf.nn.sigmoid', 'tf.nn.elu', 'tf.nn.leaky_relu', 'tf.nn.softplus', 'tf.nn.selu'])
+@pytest.mark.parametrize('activation', ['tf.nn.tanh', 'tf.nn.sigmoid', 'tf.nn.elu', 'tf.nn.leaky_relu', 'tf.nn.softplus', 'tf.nn.selu', 'tf.nn.swish', 'tf.nn.gelu'])
 @pytest.mark.parametrize('E,D,O,L,bt,units', [(2, 62, 60, 3, 64, 128), (2, 20, 17, 2, 37, 48)])
 def test_training_steps_with_other_activations(E, D, O, L, bt, units, activation):
     """mlp_params['activation'] other than relu (the reference evals any string, mlp_ensemble.py:14): the GEMM-by-GEMM trainer with
@@ -212,7 +212,7 @@ def test_training_steps_with_other_activations(E, D, O, L, bt, units, activation
     assert abs(vl - ref_vl) <= 1e-5 * max(1.0, abs(ref_vl))
 
 
-@pytest.mark.parametrize('activation,rate', [('relu', 0.2), ('tf.nn.tanh', 0.35), ('tf.nn.elu', 0.1)])
+@pytest.mark.parametrize('activation,rate', [('relu', 0.2), ('tf.nn.tanh', 0.35), ('tf.nn.elu', 0.1), ('tf.nn.swish', 0.25), ('tf.nn.gelu', 0.15)])
 def test_training_steps_with_dropout(activation, rate):
     """mlp_params['dropout_rate'] != 0 (models.yaml:13; Dropout after every hidden layer in training_step, mlp_ensemble.py:15,21,138):
     the device draws the keep masks from Philox keyed (seed, step, member, layer, row, unit); the oracle rebuilds exactly those masks

@@ -39,8 +39,20 @@ def test_activations_follow_tensorflow_definitions():
         np.testing.assert_allclose(f(z), fv, rtol=1e-12, atol=1e-15, err_msg=name)
         np.testing.assert_allclose(df(z), dv, rtol=1e-12, atol=1e-15, err_msg=name)
         assert o.activation_and_grad(name.split('.')[-1])[0](z).tolist() == f(z).tolist()      # bare names too
+    # swish (= silu) and gelu (TensorFlow's default exact form): known values — swish(1) = 0.7310585786300049, swish'(0) = 0.5,
+    # gelu(1) = Phi(1) = 0.8413447460685429, gelu'(0) = 0.5, gelu'(1) = Phi(1) + phi(1) = 1.0833154705876864 — and f' against a central difference
+    f, df = o.activation_and_grad('tf.nn.swish')
+    np.testing.assert_allclose(f(np.array([1.0, 0.0, -1.0])), [0.7310585786300049, 0.0, -0.2689414213699951], rtol=1e-14)
+    np.testing.assert_allclose(df(np.array([0.0, 1.0])), [0.5, 0.9276705118714867], rtol=1e-14)
+    assert o.activation_and_grad('tf.nn.silu')[0](z).tolist() == f(z).tolist()
+    g, dg = o.activation_and_grad('tf.nn.gelu')
+    np.testing.assert_allclose(g(np.array([1.0, 0.0, -1.0])), [0.8413447460685429, 0.0, -0.15865525393145707], rtol=1e-14)
+    np.testing.assert_allclose(dg(np.array([0.0, 1.0])), [0.5, 1.0833154705876864], rtol=1e-14)
+    for fn, dfn in ((f, df), (g, dg)):
+        zz = np.linspace(-4.0, 4.0, 41)
+        np.testing.assert_allclose(dfn(zz), (fn(zz + 1e-6) - fn(zz - 1e-6)) / 2e-6, rtol=1e-7, atol=1e-9)
     with pytest.raises(NotImplementedError):
-        o.activation_and_grad('tf.nn.swish')
+        o.activation_and_grad('tf.nn.crelu')           # (changes the layer's width: not a pointwise activation)
 
 
 def test_scale_rule():

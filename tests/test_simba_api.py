@@ -248,8 +248,8 @@ def test_predict_draws_fresh_noise_per_call():
 
 
 def test_unknown_activation_is_refused_with_a_reason():
-    with pytest.raises(NotImplementedError, match='swish'):
-        make_agent_parts('cem_mpc', activation='tf.nn.swish')
+    with pytest.raises(NotImplementedError, match='crelu'):
+        make_agent_parts('cem_mpc', activation='tf.nn.crelu')
 
 
 @pytest.mark.gpu
