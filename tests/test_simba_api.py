@@ -253,11 +253,13 @@ def test_unknown_activation_is_refused_with_a_reason():
 
 
 @pytest.mark.gpu
-def test_model_with_another_activation_fits_and_plans():
-    """models.yaml `activation: tf.nn.elu` through the simba classes: MlpEnsemble.fit on the device (the GEMM trainer), then
+@pytest.mark.parametrize('activation', ['tf.nn.elu', 'tf.nn.swish'])
+def test_model_with_another_activation_fits_and_plans(activation):
+    """models.yaml `activation: tf.nn.elu` (or tf.nn.swish — the usual choice of ensemble-dynamics papers, whose backward pass needs the kept
+    pre-activations) through the simba classes: MlpEnsemble.fit on the device (the GEMM trainer), then
     SafeCemMpc.generate_action (the generic rollout kernel) against the oracle on the FITTED weights with that activation;
     `dropout_rate: 0.1` rides along (training-time only: the planner's forward passes run with training=False, mlp_ensemble.py:127)."""
-    env, model, pol = make_agent_parts('safe_cem_mpc', seed=5, activation='tf.nn.elu', dropout_rate=0.1)   # Dropout acts in fit only
+    env, model, pol = make_agent_parts('safe_cem_mpc', seed=5, activation=activation, dropout_rate=0.1)   # Dropout acts in fit only
     assert model.model.dropout_rate == 0.1
     rng = np.random.default_rng(4)
     obs = rng.normal(0, 0.5, (400, 60)).astype(np.float32)
@@ -278,7 +280,7 @@ def test_model_with_another_activation_fits_and_plans():
     eo = rng.standard_normal(2).astype(np.float32)
     a, s = pol.do_generate_action(state, eps_act=ea, eps_model=em, eps_out=eo)
     for w in ws:
-        w['activation'] = 'tf.nn.elu'
+        w['activation'] = activation
     ocfg = o.PlanConfig(horizon=H, iterations=I, n_samples=N, n_elite=pp['n_elite'], particles=P, ensemble_size=15,
                         smoothing=pp['smoothing'], stddev_threshold=pp['stddev_threshold'], noise_stddev=pp['noise_stddev'],
                         variant='safe', posterior_mean_threashold=pp.get('posterior_mean_threashold', 0.15))
