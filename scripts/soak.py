@@ -12,7 +12,7 @@ from tests import helpers as hp
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
 
 
-def leg(name, pb, cfg, restage_every=0):
+def leg(name, pb, cfg, restage_every=0, inject_at=0):
     pl = hp.make_planner(pb, cfg)
     ref = pl.plan(pb['state'], seed=11, call=7)
     free0 = torch.cuda.mem_get_info()[0]
@@ -20,7 +20,11 @@ def leg(name, pb, cfg, restage_every=0):
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < budget:
         st = pb['state'] + 0.01 * rng.standard_normal(pb['state'].shape).astype(np.float32)
+        if inject_at and n == inject_at:                          # one fused select of this plan sees a grid barrier expire: recovered in stream,
+            mode0 = pl.select_mode(); pl.inject_fault(1)          # the handle then plans on the multi-launch select (same bits as the fused one)
         a, s, it = pl.plan(st, seed=3, call=n)
+        if inject_at and n == inject_at:
+            assert mode0 == 3 and pl.select_mode() == 2, (mode0, pl.select_mode())
         assert np.all(np.isfinite(a)) and np.isfinite(s), (name, n)
         n += 1
         if restage_every and n % restage_every == 0:
@@ -52,4 +56,8 @@ _, cfg = hp.configs(pbw, N=1000, H=20, P=5, E=5, k=100, I=4, use_graph=True)
 leg('generic kernel: 192 units, tanh', pbw, cfg)
 _, cfg = hp.configs(pb, N=24576, H=10, P=5, E=5, k=2457, I=3, use_graph=True)
 leg('fused multi-workgroup select', pb, cfg)
+leg('fused select, one expiry injected', pb, cfg, inject_at=100)
+pbs = hp.make_problem(60, 2, 15, 4, seed=2)
+_, cfg = hp.configs(pbs, N=500, H=8, P=45, E=15, k=20, I=9, variant='safe', post=0.15, noise=0.01, use_graph=True)
+leg('shipped safe_cem_mpc shape', pbs, cfg, restage_every=167)
 print('soak ok')
