@@ -662,7 +662,7 @@ const char *cem_status_string(int s)
     case CEM_ERR_NO_WEIGHTS: return "set_weights has not been called";
     case CEM_ERR_STATE: return "stepwise plan calls out of order, or a standalone call while a plan is in flight";
     case CEM_ERR_COMM: return "RCCL: library not found or a collective call failed (see cem_last_hip_error for the ncclResult_t)";
-    case CEM_ERR_DEVICE: return "a kernel could not finish its work (floating rollout segment starved of its work-queue entry): result not valid";
+    case CEM_ERR_DEVICE: return "a kernel could not finish its work (a floating rollout segment starved of its work-queue entry, or an expired fused-select barrier whose recovery did not run): result not valid";
     default: return "unknown status";
     }
 }
