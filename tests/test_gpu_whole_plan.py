@@ -26,7 +26,7 @@ SCORE_ATOL = 2e-5            # H = 30-50 recurrent fp32 steps on either side (te
 MAX_FLIPPED = 0.03           # share of candidates a one-sided threshold crossing may move by a whole unit
 
 
-def whole_plan_vs_oracle(name, O, A, K, N, H, I, variant, k, seed, call=3, post=0.3, pb_seed=1234, verbose=True):
+def whole_plan_vs_oracle(name, O, A, K, N, H, I, variant, k, seed, call=3, post=0.3, pb_seed=1234, verbose=True, allow_near_ties=False):
     """Returns a dict of what was measured (for scripts/scan_whole_plan_seeds.py); raises AssertionError on any mismatch."""
     import torch
     assert torch.cuda.is_available(), 'gpu tests need an MI355X'
@@ -82,6 +82,12 @@ def whole_plan_vs_oracle(name, O, A, K, N, H, I, variant, k, seed, call=3, post=
         el = np.sort(pl.elite_idx().cpu().numpy())
         same = np.array_equal(el, np.sort(trace[it]['elite']))
         out['elites_equal'].append(bool(same))
+        if not same and allow_near_ties and it == I - 1:
+            # (the scan over 65 536 candidates: two scores within rounding of each other on the k-th place may swap; only admissible on the
+            #  LAST iteration, where nothing is refitted from the set any more, and only if every swapped candidate is within rounding of the k-th score)
+            assert hp.elite_sets_equal_modulo_ties(trace[it]['scores'], el, trace[it]['elite'], SCORE_ATOL), 'elite sets differ by more than a near-tie'
+            out['near_tie_swaps'] = len(set(el.tolist()) ^ set(trace[it]['elite'].tolist())) // 2
+            continue
         assert same, ('%s %s iteration %d: the elite sets differ in %d candidates (a threshold crossing on the elite boundary: '
                       'pick another seed with scripts/scan_whole_plan_seeds.py)' % (name, variant, it, len(set(el) ^ set(trace[it]['elite']))))
         ms = pl.mu_sigma().cpu().numpy()
@@ -94,6 +100,8 @@ def whole_plan_vs_oracle(name, O, A, K, N, H, I, variant, k, seed, call=3, post=
     # 4. the graph plan IS that plan, and its result is the oracle's
     np.testing.assert_array_equal(a_g, a_s)
     assert s_g == s_s and it_g == it_s == I
+    if 'near_tie_swaps' in out:
+        out['elites_equal'][-1] = 'modulo %d near-tie swap(s) on the k-th place' % out['near_tie_swaps']
     np.testing.assert_array_equal(ms_g, pl.mu_sigma().cpu().numpy())
     np.testing.assert_array_equal(el_g, np.sort(pl.elite_idx().cpu().numpy()))
     np.testing.assert_allclose(a_g, ra, rtol=1e-5, atol=1e-7, err_msg='%s %s: returned action' % (name, variant))
@@ -103,7 +111,7 @@ def whole_plan_vs_oracle(name, O, A, K, N, H, I, variant, k, seed, call=3, post=
     if verbose:
         print('%s %s seed %d: %d iterations at full width: elite sets equal in every iteration; flipped candidates per iteration %s; '
               'max score error %.3g; max |mu| err %.3g, |sigma| err %.3g; action rel err %.3g'
-              % (name, variant, seed, I, out['flipped'], max(out['score_err']), max(out['mu_err']), max(out['sigma_err']), out['action_rel_err']))
+              % (name, variant, seed, I, out['flipped'], max(out['score_err']), max(out['mu_err'] or [0]), max(out['sigma_err'] or [0]), out['action_rel_err']))
     pl.close()
     return out
 
