@@ -383,7 +383,11 @@ __device__ __forceinline__ void cem_mfma_stage(f4 (&acc0)[RC], f4 (&acc1)[RC], f
             for (int Q = NOWN; Q < KF; ++Q) {
                 const bool now = (P == 1) ? (Q <= 1 + LA) : (Q == P + LA);
                 if (now) {
+#ifdef CEM_DBG_STATICADDR      // timing-only diagnostic: block index without the wave's role in it (compile-time LDS offsets: WRONG results) — what the per-read address arithmetic costs
+                    const int F = Q;
+#else
                     const int F = L0IN ? cem_perm_l0(w, KF / 4, Q) : cem_perm_hidden(w, Q);
+#endif
 #pragma unroll
                     for (int c = 0; c < RC; ++c)
 #ifdef CEM_DBG_NOLDSREAD
